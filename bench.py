@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the quantized-inference hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1], the config the metric is quoted on): masked-MHA decode,
+Llama-2-7B shape (32 q heads = 32 kv heads, Dh 128), batch 64, ctx 2048, paged bf16 KV
+(tokens_per_block 64), RoPE + cache append fused, through the GPTAttention plugin enqueue of the
+C ABI.  One "step" = one enqueue over the whole batch (one layer's decode attention).  K/V for one
+step is 2.15 GB, far beyond the 256 MB Infinity Cache, so the rate is an HBM rate.
+`value` = algorithmic bytes of all ranks / max-over-ranks time; inputs are
+resident in HBM before the timed region.  Secondary numbers of the same metric family (W4A16 GEMV
+GB/s with >= 64 rotating weight sets, SmoothQuant int8 GEMM TOP/s) ride along under "secondary".
+
+N>1: attention shards by KV head / sequence with no collective -> every rank runs the
+same per-GPU workload on its own cache, weak scaling, no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (_ROOT, os.path.join(_ROOT, "tensorrt-llm_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+INT8_PEAK_TOPS = 5000.0    # dense int8 MFMA = 2x bf16 (2.5 PF)
+
+
+def build_attention_case(dev, B=64, H=32, D=128, ctx=2048, tpb=64, seed=42):
+    from mi355q import functional as F
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    nblk = B * (ctx // tpb)
+    pool = (torch.randn(nblk, 2, H, tpb, D, generator=g, dtype=torch.float32) * 0.5).to(torch.bfloat16).to(dev)
+    perm = torch.randperm(nblk, generator=g).reshape(B, ctx // tpb)   # shuffled block table
+    be = H * tpb * D * 2
+    ptrs = (torch.stack([perm * 2 * be, perm * 2 * be + be], 1) + pool.data_ptr()).reshape(1, B, 2, -1)
+    qkv = torch.randn(B, 1, 3 * H * D, generator=g).to(torch.bfloat16).to(dev)
+    seq = torch.full((B,), ctx, dtype=torch.int32)
+    plg = F.make_gpt_attention_plugin(num_heads=H, num_kv_heads=H, head_size=D, dtype="bfloat16",
+                                      position_embedding_type=2, rotary_embedding_dim=D, tokens_per_block=tpb)
+    inputs = [qkv, seq.to(dev), seq - 1, torch.tensor([ctx], dtype=torch.int32), torch.zeros(1, dtype=torch.int32),
+              (seq - 1).to(dev), torch.zeros(B, 1, ctx, dtype=torch.int32, device=dev),
+              torch.ones(B, dtype=torch.int32), ptrs.to(dev), ptrs]
+    out = torch.empty(B, 1, H * D, dtype=torch.bfloat16, device=dev)
+    plg.configure(inputs)
+    ws_bytes = plg.get_workspace_size(inputs, [out])
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    # K+V read + qkv in + out + appended k,v
+    algo_bytes = 2 * B * H * ctx * D * 2 + B * 3 * H * D * 2 + B * H * D * 2 + 2 * B * H * D * 2
+    keep = (pool, ptrs)
+    return plg, inputs, out, ws, algo_bytes, keep
+
+
+def time_steps(fn, steps, warmup, barrier):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, e0.elapsed_time(e1) / 1e3   # seconds: host wall, device (HIP events on the launch stream)
+
+
+def bench_gemv(dev, steps, m=1, n=4096, k=4096, g=128, sets=72, pre_quant=False):
+    """cfg1: W4A16 AWQ GEMV with zeros + pre-quant scale; `sets` independent weight sets (> 256 MB
+    in total) are cycled so the rate is HBM, not Infinity Cache."""
+    from mi355q import _lib as L
+    from mi355q import functional as F
+    import ctypes as C
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    w = torch.randint(-128, 128, (sets, k, n // 2), dtype=torch.int8, device=dev)   # any bytes are valid int4 tiles
+    scale = torch.rand(sets, k // g, n, dtype=dt, device=dev)
+    zero = torch.randn(sets, k // g, n, dtype=dt, device=dev)
+    pre = torch.rand(1, k, dtype=dt, device=dev)
+    act = torch.randn(m, k, dtype=dt, device=dev)
+    out = torch.empty(m, n, dtype=dt, device=dev)
+    ws_bytes = L.lib().mi355q_weight_only_gemm_workspace_size(m, n, k, L.WEIGHT_INT4)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    params = []
+    for s in range(sets):
+        p = L.WeightOnlyParams()
+        p.qweight, p.scales, p.zeros = w[s].data_ptr(), scale[s].data_ptr(), zero[s].data_ptr()
+        p.in_, p.act_scale, p.bias, p.out = act.data_ptr(), (pre.data_ptr() if pre_quant else None), None, out.data_ptr()
+        p.m, p.n, p.k, p.group_size = m, n, k, g
+        p.weight_type, p.act_type = L.WEIGHT_INT4, L.BF16
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
+        params.append(p)
+    stream = torch.cuda.current_stream().cuda_stream
+    fn = L.lib().mi355q_weight_only_gemm
+    state = {"i": 0}
+
+    def step():
+        rc = fn(C.byref(params[state["i"] % sets]), C.c_void_p(stream))
+        state["i"] += 1
+        assert rc == 0, L.lib().mi355q_last_error()
+
+    _, dev_s = time_steps(step, steps, sets, lambda: None)
+    algo = k * n // 2 + 2 * (k // g) * n * 2 + (k * 2 if pre_quant else 0) + 2 * m * (k + n)
+    return {"m": m, "n": n, "k": k, "flags": "ZERO+PRE_QUANT_SCALE (2 kernels)" if pre_quant else "ZERO", "us_per_call": dev_s / steps * 1e6, "GBps": algo / (dev_s / steps) / 1e9,
+            "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo,
+            "weight_sets": sets}
+
+
+def bench_int8_gemm(dev, steps, m=4096, n=13824, k=5120):
+    """cfg3: SmoothQuant W8A8 GEMM, Llama-2-13B gate/up shape, per-token x per-channel, fp16 out."""
+    from mi355q import functional as F
+    torch.manual_seed(0)
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8, device=dev)
+    b = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=dev)
+    sa = (torch.randint(1, 10, (m, 1), device=dev).float() * 1e-2)
+    sb = (torch.randint(1, 10, (1, n), device=dev).float() * 1e-2)
+    plg = F.Plugin("SmoothQuantGemm", [("has_per_channel_scaling", 1, 5), ("has_per_token_scaling", 1, 5),
+                                       ("type_id", 1, 5)])
+    out = torch.empty(m, n, dtype=torch.float16, device=dev)
+    ins = [a, b, sa, sb]
+    _, dev_s = time_steps(lambda: plg.enqueue(ins, [out]), steps, 2, lambda: None)
+    ops = 2.0 * m * n * k
+    return {"m": m, "n": n, "k": k, "ms_per_call": dev_s / steps * 1e3, "TOPS": ops / (dev_s / steps) / 1e12,
+            "frac_of_int8_peak": ops / (dev_s / steps) / 1e12 / INT8_PEAK_TOPS}
+
+
+def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
+    """The oracle (CPU port of the MMHA math) on the same workload shape (`seqs` of the 64 sequences
+    x 32 heads x ctx 2048), timed on the host cores torch uses; best of `reps` passes (bounded to a
+    few tens of seconds)."""
+    import oracle
+    torch.manual_seed(42)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box gives one GPU's share: 16 CPUs
+    cache = oracle.PagedKVCache(seqs, H, D, ctx, tpb, torch.bfloat16)
+    cache.pool.copy_((torch.randn(cache.pool.shape) * 0.5).to(torch.bfloat16))
+    qkv = torch.randn(seqs, 3 * H * D).to(torch.bfloat16)
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.decode_attention(qkv, cache, [ctx] * seqs, H, H, D, rope="neox", rot_dim=D, update_cache=False)
+        best = min(best, time.perf_counter() - t0)
+    nbytes = seqs * (2 * H * ctx * D * 2 + 3 * H * D * 2 + H * D * 2 + 2 * H * D * 2)
+    return {"value": nbytes / best / 1e9, "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{seqs} of 64 sequences x {H} heads x ctx {ctx}, oracle.decode_attention, "
+                      f"best of {reps} passes = {best:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the GEMV / int8 GEMM side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        barrier = lambda: dist.barrier()
+    else:
+        barrier = lambda: None
+
+    B, H, D, ctx, tpb = 64, 32, 128, 2048, 64
+    plg, inputs, out, ws, algo_bytes, keep = build_attention_case(dev, B, H, D, ctx, tpb, seed=42 + rank)
+    step = lambda: plg.enqueue(inputs, [out], ws)
+    wall, dev_s = time_steps(step, args.steps, args.warmup, barrier)
+
+    t = torch.tensor([wall, dev_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, dev_max = t.tolist()
+
+    if rank == 0:
+        per_launch = dev_s / args.steps
+        achieved = algo_bytes / per_launch / 1e9
+        res = {
+            "metric": "W4A16 GEMV HBM GB/s + paged decode-attn GB/s + int8 GEMM TFLOPS, Llama shapes",
+            "value": world * algo_bytes * args.steps / wall_max / 1e9,
+            "unit": "GB/s (paged decode attention, algorithmic bytes, whole job)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 (KV + q/out), fp32 accumulate", "data": "synthetic",
+            "config": {"workload": "masked-MHA decode, Llama-2-7B shape: 32 heads x d128, batch 64, ctx 2048, "
+                                   "paged bf16 KV (tokens_per_block 64), RoPE + KV append fused; one step = one "
+                                   "GPTAttention enqueue (one layer)",
+                       "batch_per_gpu": B, "heads": H, "head_dim": D, "ctx": ctx, "tokens_per_block": tpb,
+                       "parallelism": f"{world} independent KV-head/sequence shards, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "decode_attn_kernel<bf16, kv=bf16, Dh=128, G=1, U=8>",
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": per_launch * 1e6},
+        }
+        if not args.no_secondary:
+            sec = {}
+            try:
+                sec["w4a16_gemv"] = [bench_gemv(dev, 4 * 72, m=1), bench_gemv(dev, 4 * 72, m=1, pre_quant=True),
+                                     bench_gemv(dev, 4 * 72, m=16),
+                                     bench_gemv(dev, 2 * 72, m=1, n=11008, k=4096, sets=24),
+                                     bench_gemv(dev, 2 * 72, m=1, n=4096, k=11008, sets=24)]
+                sec["int8_gemm"] = bench_int8_gemm(dev, 10)
+            except Exception as e:  # secondary numbers must never take the headline down
+                sec["error"] = repr(e)
+            res["secondary"] = sec
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_attention(H, D, ctx, tpb)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+/*
+ * mi355q.h -- C ABI of libmi355q.so: MI355X (gfx950) implementation of TensorRT-LLM's
+ * quantized-inference hot path behind the reference's own plugin / launcher contracts.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * tree).  All pointers in `inputs` / `outputs` / `workspace` are DEVICE pointers unless the
+ * reference marks the tensor HOST_* (GPTAttention); `stream` is a hipStream_t passed as void*.
+ * Functions return MI355Q_OK (0) or a negative status; the message is in mi355q_last_error()
+ * (thread-local).  No entry point allocates device memory; enqueue calls never synchronise.
+ */
+#ifndef MI355Q_H
+#define MI355Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+    /* ---- status: replaces TLLM_CHECK / TllmException + caughtError (plugins/common/plugin.cpp) */
+    typedef enum
+    {
+        MI355Q_OK = 0,
+        MI355Q_ERR_INVALID_ARGUMENT = -1, /* TLLM_CHECK failure */
+        MI355Q_ERR_UNSUPPORTED = -2,      /* TLLM_THROW("... unsupported ...") */
+        MI355Q_ERR_HIP = -3,              /* check_cuda_error */
+        MI355Q_ERR_INTERNAL = -4
+    } mi355q_status;
+
+    const char* mi355q_last_error(void);
+    const char* mi355q_version(void);
+
+    /* ---- nvinfer1::DataType / Dims / PluginTensorDesc / PluginField, layout-compatible subsets */
+    enum
+    {
+        MI355Q_FLOAT = 0,
+        MI355Q_HALF = 1,
+        MI355Q_INT8 = 2,
+        MI355Q_INT32 = 3,
+        MI355Q_BOOL = 4,
+        MI355Q_UINT8 = 5,
+        MI355Q_FP8 = 6,
+        MI355Q_BF16 = 7,
+        MI355Q_INT64 = 8
+    };
+
+    typedef struct
+    {
+        int32_t nbDims;
+        int32_t d[8];
+    } mi355q_dims; /* nvinfer1::Dims */
+
+    typedef struct
+    {
+        mi355q_dims dims;
+        int32_t type;   /* nvinfer1::DataType */
+        int32_t format; /* nvinfer1::TensorFormat, 0 = kLINEAR */
+        float scale;
+    } mi355q_tensor_desc; /* nvinfer1::PluginTensorDesc */
+
+    typedef struct
+    {
+        mi355q_tensor_desc desc;
+        mi355q_dims min;
+        mi355q_dims max;
+    } mi355q_dynamic_tensor_desc; /* nvinfer1::DynamicPluginTensorDesc */
+
+    enum
+    {
+        MI355Q_FIELD_FLOAT16 = 0,
+        MI355Q_FIELD_FLOAT32 = 1,
+        MI355Q_FIELD_FLOAT64 = 2,
+        MI355Q_FIELD_INT8 = 3,
+        MI355Q_FIELD_INT16 = 4,
+        MI355Q_FIELD_INT32 = 5
+    }; /* nvinfer1::PluginFieldType */
+
+    typedef struct
+    {
+        const char* name;
+        const void* data;
+        int32_t type;
+        int32_t length;
+    } mi355q_plugin_field; /* nvinfer1::PluginField */
+
+    /* ---- plugin objects: IPluginCreator::createPlugin / deserializePlugin + IPluginV2DynamicExt.
+     * Names and field names are the reference's:
+     *   "WeightOnlyGroupwiseQuantMatmul" {type_id, quant_algo, group_size}
+     *        plugins/weightOnlyGroupwiseQuantMatmulPlugin/weightOnlyGroupwiseQuantMatmulPlugin.cpp:581-648
+     *   "WeightOnlyQuantMatmul"          {type_id, weight_type_id}
+     *        plugins/weightOnlyQuantMatmulPlugin/weightOnlyQuantMatmulPlugin.cpp:409-460
+     *   "SmoothQuantGemm"                {has_per_channel_scaling, has_per_token_scaling, type_id}
+     *        plugins/smoothQuantGemmPlugin/smoothQuantGemmPlugin.cpp:314-370
+     *   "QuantizePerToken"               {} plugins/quantizePerTokenPlugin/quantizePerTokenPlugin.cpp
+     *   "GPTAttention"                   {layer_idx, num_heads, ... is_medusa_enabled}
+     *        plugins/gptAttentionCommon/gptAttentionCommon.cpp:1561-1593, gptAttentionPlugin.cpp:700-790
+     *   "Fp8Gemm"  (no reference plugin: TensorRT fuses Q/DQ+matmul) {type_id}
+     * Weight tensors handed to enqueue are in the layout mi355q_preprocess_weights_for_mixed_gemm
+     * produces for MI355Q_LAYOUT_GFX950 (the arch-selected layout, as the reference selects per SM). */
+    typedef struct mi355q_plugin mi355q_plugin;
+
+    /* IPluginCreator::createPlugin(name, PluginFieldCollection*) */
+    mi355q_status mi355q_plugin_create(
+        const char* name, const mi355q_plugin_field* fields, int32_t nbFields, mi355q_plugin** out);
+    /* IPluginCreator::deserializePlugin(name, data, length) */
+    mi355q_status mi355q_plugin_deserialize(const char* name, const void* data, size_t length, mi355q_plugin** out);
+    /* IPluginV2::destroy / clone / getPluginType / getNbOutputs */
+    void mi355q_plugin_destroy(mi355q_plugin* p);
+    mi355q_status mi355q_plugin_clone(const mi355q_plugin* p, mi355q_plugin** out);
+    const char* mi355q_plugin_type(const mi355q_plugin* p);
+    int32_t mi355q_plugin_nb_outputs(const mi355q_plugin* p);
+    /* IPluginV2DynamicExt::getOutputDimensions (constant dims only) */
+    mi355q_status mi355q_plugin_get_output_dimensions(
+        const mi355q_plugin* p, int32_t outputIndex, const mi355q_dims* inputs, int32_t nbInputs, mi355q_dims* out);
+    /* IPluginV2DynamicExt::supportsFormatCombination; returns 1 / 0, negative on error */
+    int32_t mi355q_plugin_supports_format_combination(
+        const mi355q_plugin* p, int32_t pos, const mi355q_tensor_desc* inOut, int32_t nbInputs, int32_t nbOutputs);
+    /* IPluginV2Ext::getOutputDataType; returns the DataType code, negative on error */
+    int32_t mi355q_plugin_get_output_data_type(
+        const mi355q_plugin* p, int32_t index, const int32_t* inputTypes, int32_t nbInputs);
+    /* IPluginV2DynamicExt::configurePlugin */
+    mi355q_status mi355q_plugin_configure(mi355q_plugin* p, const mi355q_dynamic_tensor_desc* in, int32_t nbInputs,
+        const mi355q_dynamic_tensor_desc* out, int32_t nbOutputs);
+    /* IPluginV2DynamicExt::getWorkspaceSize */
+    size_t mi355q_plugin_get_workspace_size(const mi355q_plugin* p, const mi355q_tensor_desc* inputs, int32_t nbInputs,
+        const mi355q_tensor_desc* outputs, int32_t nbOutputs);
+    /* IPluginV2DynamicExt::enqueue -- the hot call.  Returns 0 on success like the reference. */
+    int32_t mi355q_plugin_enqueue(mi355q_plugin* p, const mi355q_tensor_desc* inputDesc,
+        const mi355q_tensor_desc* outputDesc, const void* const* inputs, void* const* outputs, void* workspace,
+        void* stream);
+    /* IPluginV2::getSerializationSize / serialize */
+    size_t mi355q_plugin_get_serialization_size(const mi355q_plugin* p);
+    mi355q_status mi355q_plugin_serialize(const mi355q_plugin* p, void* buffer);
+    /* getPluginCreators(int32_t&) (plugins/api/tllmPlugin.h:47-56): NULL-terminated list of names */
+    const char* const* mi355q_get_plugin_names(int32_t* nbPlugins);
+
+    /* ---- host-side weight tooling: cpp/tensorrt_llm/thop/weightOnlyQuantOp.cpp (CPU tensors) */
+    enum
+    {
+        MI355Q_WEIGHT_INT8 = 1, /* WeightTypeId::INT8  weightOnlyQuantMatmulPlugin.h:38-42 */
+        MI355Q_WEIGHT_INT4 = 2
+    };
+    enum
+    {
+        MI355Q_LAYOUT_ROW_MAJOR = 0,         /* unprocessed [K, N] (int4: [K, N/2], low nibble = even column) */
+        MI355Q_LAYOUT_REF_SM80 = 1,          /* ColumnMajorTileInterleave<64, 2|4> + permute + bias */
+        MI355Q_LAYOUT_REF_SM90 = 2,          /* plain column-major, signed */
+        MI355Q_LAYOUT_GFX950 = 3             /* this library's MFMA-fragment-major layout */
+    };
+    /* thop preprocess_weights_for_mixed_gemm (weightOnlyQuantOp.cpp:116-141) /
+     * cutlass_preprocessors.cpp:535-584.  shape = {experts, K, N} in ELEMENTS; src is ROW_MAJOR;
+     * dst receives `layout`.  HOST pointers. */
+    mi355q_status mi355q_preprocess_weights_for_mixed_gemm(
+        int8_t* dst, const int8_t* src, const size_t shape[3], int32_t weight_type, int32_t layout);
+    /* Inverse: any layout -> ROW_MAJOR (ingest reference-preprocessed checkpoints).  HOST pointers. */
+    mi355q_status mi355q_unprocess_weights_for_mixed_gemm(
+        int8_t* dst, const int8_t* src, const size_t shape[3], int32_t weight_type, int32_t layout);
+    /* thop unpack_int4_packed_tensor_to_int8 / pack_int8_tensor_to_packed_int4 (:274-343). HOST. */
+    mi355q_status mi355q_unpack_int4_packed_tensor_to_int8(int8_t* dst, const int8_t* src, size_t numPacked);
+    mi355q_status mi355q_pack_int8_tensor_to_packed_int4(int8_t* dst, const int8_t* src, size_t numPacked);
+    /* symmetric_quantize<float-scales, float-weights> (cutlass_preprocessors.cpp:621-729).  HOST.
+     * unprocessed may be NULL.  processed is written in `layout`. */
+    mi355q_status mi355q_symmetric_quantize(int8_t* processed, int8_t* unprocessed, float* scales,
+        const float* weight, const size_t shape[3], int32_t weight_type, int32_t layout);
+
+    /* ---- kernel launchers (layer 2 of the reference), device pointers */
+
+    /* kernels/weightOnlyBatchedGemv/common.h:63-106 WeightOnlyParams + kernelLauncher.cu:122
+     * weight_only_batched_gemv_launcher, and CutlassFpAIntBGemmRunner::gemm
+     * (kernels/cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm.h:54-137): one struct, any m. */
+    typedef struct
+    {
+        const void* qweight;   /* MI355Q_LAYOUT_GFX950 */
+        const void* scales;    /* [k/group, n] (group-wise) or [n] (per-channel), act dtype */
+        const void* zeros;     /* [k/group, n] additive, act dtype, or NULL */
+        const void* in;        /* [m, k] act dtype */
+        const void* act_scale; /* [k] pre-quant scale or NULL */
+        const void* bias;      /* [n] or NULL */
+        void* out;             /* [m, n] act dtype */
+        int32_t m, n, k;
+        int32_t group_size;    /* 64 / 128, or 0 == per-channel */
+        int32_t weight_type;   /* MI355Q_WEIGHT_INT8 / INT4 */
+        int32_t act_type;      /* MI355Q_HALF / MI355Q_BF16 */
+        void* workspace;       /* smoothed activations (m*k, 256-B aligned) + split-K slabs; may be NULL
+                                  when act_scale is NULL (split-K is then skipped) */
+        size_t workspace_bytes;
+    } mi355q_weight_only_params;
+    /* CutlassFpAIntBGemmRunner::getWorkspaceSize + the plugin's smoothed-activation area
+     * (weightOnlyGroupwiseQuantMatmulPlugin.cpp:330-332) */
+    size_t mi355q_weight_only_gemm_workspace_size(int32_t max_m, int32_t n, int32_t k, int32_t weight_type);
+    mi355q_status mi355q_weight_only_gemm(const mi355q_weight_only_params* params, void* stream);
+    /* Dequantise the GFX950 layout back to a dense [k, n] act-dtype matrix on the device
+     * (the reference tests do this with an identity matmul, test_weight_only_quant_matmul.py:44-53). */
+    mi355q_status mi355q_weight_only_dequantize(const mi355q_weight_only_params* params, void* stream);
+
+    /* kernels/preQuantScaleKernel.cu:26-136 apply_per_channel_scale_kernel_launcher */
+    mi355q_status mi355q_apply_per_channel_scale(
+        void* out, const void* act, const void* scale, int32_t rows, int32_t cols, int32_t act_type, void* stream);
+
+    /* kernels/cutlass_kernels/int8_gemm/int8_gemm.h:43-89 CutlassInt8GemmRunner<T>::gemm:
+     * C[m,n] = cvt(float(sum_k A[m,k]*B[n,k]) * (alphaCol[n] * alphaRow[m])) */
+    mi355q_status mi355q_int8_gemm(const int8_t* A, const int8_t* B, int32_t per_token, int32_t per_channel,
+        const float* alphaCol, const float* alphaRow, void* C, int32_t out_type, int32_t m, int32_t n, int32_t k,
+        void* stream);
+
+    /* kernels/quantization.cu:118-127 invokePerTokenQuantization */
+    mi355q_status mi355q_per_token_quantization(int8_t* dst, const void* src, int64_t numRows, int64_t numCols,
+        float* scalePtr, int32_t src_type, void* stream);
+
+    /* FP8 e4m3 (OCP) GEMM: C[m,n] = cvt((sum_k A[m,k]*B[n,k]) * (scaleA*scaleB)); replaces the
+     * TensorRT Q/DQ fusion / cuBLASLt fp8 path (plugins/gemmPlugin/gemmPlugin.cpp:193-198). */
+    mi355q_status mi355q_fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C,
+        int32_t out_type, int32_t m, int32_t n, int32_t k, void* stream);
+    /* thop/fp8Op.cpp quantize_e4m3_{activation,weight,per_tensor}: mode 0 per-row (scales [rows]),
+     * 1 per-col (scales [cols]), 2 per-tensor (scales must hold TWO floats: [0] receives the scale,
+     * [1] is scratch for the amax pass). */
+    mi355q_status mi355q_quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols,
+        int32_t src_type, int32_t mode, void* stream);
+
+    /* kernels/decoderMaskedMultiheadAttention.h:76-244 Multihead_attention_params +
+     * masked_multihead_attention(params, KVBlockArray, ...): one generation step over a paged cache. */
+    typedef struct
+    {
+        const void* qkv;            /* [batch, (Hq+2Hkv)*Dh] act dtype; q | k | v */
+        const void* qkv_bias;       /* [(Hq+2Hkv)*Dh] or NULL */
+        void* out;                  /* [batch, Hq*Dh] act dtype */
+        const int32_t* sequence_lengths; /* device [batch]: kv length INCLUDING the current token */
+        const int64_t* block_pointers;   /* device [batch, 2, max_blocks_per_seq] block addresses (KVBlockArray::data) */
+        const float* kv_scale_orig_quant; /* device [1] or NULL */
+        const float* kv_scale_quant_orig; /* device [1] or NULL */
+        void* workspace;            /* mi355q_decode_attention_workspace_size bytes */
+        size_t workspace_bytes;
+        int32_t batch, num_heads, num_kv_heads, head_size;
+        int32_t max_blocks_per_seq, tokens_per_block;
+        int32_t max_seq_len;        /* upper bound of sequence_lengths (host knows it: max past kv len + 1) */
+        int32_t act_type;           /* MI355Q_HALF / MI355Q_BF16 */
+        int32_t kv_type;            /* act_type, MI355Q_INT8 or MI355Q_FP8 */
+        int32_t position_embedding_type; /* PositionEmbeddingType, kernels/gptKernels.h:40-50 */
+        int32_t rotary_embedding_dim;
+        float rotary_embedding_base;
+        int32_t rotary_embedding_scale_type; /* RotaryScalingType :52-57 */
+        float rotary_embedding_scale;
+        int32_t rotary_embedding_max_positions;
+        float q_scaling;
+        int32_t multi_block_mode;   /* 0: heuristic, >0: force that many kv splits */
+    } mi355q_decode_attention_params;
+    size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
+    mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);
+
+    enum
+    {
+        MI355Q_AR_RING = 0,
+        MI355Q_AR_ONESHOT = 1,
+        MI355Q_AR_TWOSHOT = 2,
+        MI355Q_AR_AUTO = 3
+    }; /* AllReduceStrategyType, kernels/customAllReduceKernels.h */
+    /* AllreducePlugin::selectImplementation (plugins/ncclPlugin/allreducePlugin.cpp:111-139) */
+    int32_t mi355q_allreduce_select_implementation(size_t messageBytes, int32_t worldSize, size_t maxWorkspaceBytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355Q_H */

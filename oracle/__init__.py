@@ -1,0 +1,423 @@
+"""CPU oracle for the quantized-inference hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package, and only as the checker.  The product (``tensorrt-llm_amd/``) never imports it.
+
+Two halves:
+  * ``oracle.c`` (compiled to ``liboracle.so`` by ``oracle/Makefile``): the integer / bit-level
+    restatement (int4 pack/unpack, SM80 layout pipeline, symmetric quantizer, single-rounding
+    dequantisation, int32 GEMM accumulators, per-token quantisation).
+  * this file: numpy/torch restatements of the reference's *test references* for floating-point
+    outputs (tests/quantization/_utils.py, tests/attention/test_gpt_attention.py) and of the MMHA
+    kernel's softmax conventions.
+
+Pinning: see the header of oracle.c.  "parity unpinned" items are flagged where they are defined.
+All reference paths are relative to /root/reference/.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# nvinfer1::DataType codes (also used by include/mi355q.h)
+kFLOAT, kHALF, kINT8, kINT32, kFP8, kBF16 = 0, 1, 2, 3, 6, 7
+INT8_W, INT4_W = 1, 2  # WeightTypeId, weightOnlyQuantMatmulPlugin.h:38-42
+
+_c = ctypes
+_vp, _sz, _i = _c.c_void_p, _c.c_size_t, _c.c_int
+
+
+def build():
+    """Compile liboracle.so (gcc); building the checker is not using it."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_pack_int4.restype = _i
+        _LIB.orc_preprocess_weights_for_mixed_gemm.restype = _i
+    return _LIB
+
+
+def _p(a):
+    return _vp(a.ctypes.data)
+
+
+def torch_dtype_code(dt):
+    return {torch.float16: kHALF, torch.bfloat16: kBF16}[dt]
+
+
+def _bits16(t):
+    """torch fp16/bf16 tensor -> numpy uint16 view of its bits."""
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def _from_bits16(a, dt):
+    return torch.from_numpy(a.view(np.int16).copy()).view(dt)
+
+
+# ----------------------------------------------------------------------------- int4 pack / unpack
+def unpack_int4_packed_tensor_to_int8(packed):
+    """thop/weightOnlyQuantOp.cpp:274-306.  numpy int8 [..., n] -> int8 [..., 2n]."""
+    packed = np.ascontiguousarray(packed, dtype=np.int8)
+    out = np.empty(packed.shape[:-1] + (packed.shape[-1] * 2,), np.int8)
+    lib().orc_unpack_int4(_p(packed), _p(out), _sz(packed.size))
+    return out
+
+
+def pack_int8_tensor_to_packed_int4(unpacked):
+    """thop/weightOnlyQuantOp.cpp:308-343."""
+    unpacked = np.ascontiguousarray(unpacked, dtype=np.int8)
+    assert unpacked.shape[-1] % 2 == 0
+    out = np.empty(unpacked.shape[:-1] + (unpacked.shape[-1] // 2,), np.int8)
+    if lib().orc_pack_int4(_p(unpacked), _p(out), _sz(out.size)) != 0:
+        raise ValueError("Value in unpacked tensor not in int4 range")
+    return out
+
+
+# ----------------------------------------------------------------------------- layout pipeline
+def _bits(quant_type):
+    return 8 if quant_type == INT8_W else 4
+
+
+def permute_B_rows_for_mixed_gemm(w, rows, cols, quant_type):
+    w = np.ascontiguousarray(w).view(np.uint8)
+    out = np.empty_like(w)
+    lib().orc_permute_B_rows(_p(w), _p(out), _sz(rows), _sz(cols), _i(_bits(quant_type)))
+    return out
+
+
+def subbyte_transpose(w, rows, cols, quant_type):
+    w = np.ascontiguousarray(w).view(np.uint8)
+    out = np.empty_like(w).reshape(cols, -1)
+    lib().orc_subbyte_transpose(_p(w), _p(out), _sz(rows), _sz(cols), _i(_bits(quant_type)))
+    return out
+
+
+def interleave_column_major_tensor(w, rows, cols, quant_type, rows_per_tile=64, interleave=None):
+    interleave = interleave or (2 if quant_type == INT8_W else 4)
+    w = np.ascontiguousarray(w).view(np.uint8)
+    out = np.empty_like(w)
+    lib().orc_interleave_column_major(
+        _p(w), _p(out), _sz(rows), _sz(cols), _i(_bits(quant_type)), _i(rows_per_tile), _i(interleave))
+    return out
+
+
+def add_bias_and_interleave_int8s(w):
+    out = np.ascontiguousarray(w).view(np.uint8).copy()
+    lib().orc_add_bias_and_interleave_int8(_p(out), _sz(out.size))
+    return out
+
+
+def add_bias_and_interleave_int4s(w):
+    out = np.ascontiguousarray(w).view(np.uint8).copy()
+    lib().orc_add_bias_and_interleave_int4(_p(out), _sz(out.size * 2))
+    return out
+
+
+def preprocess_weights_for_mixed_gemm(w, quant_type, arch=80):
+    """cutlass_preprocessors.cpp:535-584.  w: int8 [K, N] (int8) or [K, N/2] (packed int4), or with
+    a leading expert dim.  Returns an int8 array of the same shape (bytes re-laid out)."""
+    w = np.ascontiguousarray(w, dtype=np.int8)
+    experts = 1 if w.ndim == 2 else w.shape[0]
+    rows = w.shape[-2]
+    cols = w.shape[-1] * (8 // _bits(quant_type))
+    out = np.empty_like(w)
+    rc = lib().orc_preprocess_weights_for_mixed_gemm(
+        _p(w), _p(out), _sz(experts), _sz(rows), _sz(cols), _i(quant_type), _i(arch))
+    if rc != 0:
+        raise ValueError("unsupported shape/arch for preprocess_weights_for_mixed_gemm")
+    return out
+
+
+def symmetric_quantize(weight, quant_type):
+    """cutlass_preprocessors.cpp:621-729 / thop `_symmetric_quantize_last_axis_of_batched_matrix`.
+    weight: torch [K, N] (or [E, K, N]) fp32/fp16/bf16.  Returns (unprocessed int8 numpy,
+    scales torch in weight.dtype).  The processed layout is `preprocess_weights_for_mixed_gemm`."""
+    wf = weight.float().contiguous().numpy()
+    experts = 1 if wf.ndim == 2 else wf.shape[0]
+    rows, cols = wf.shape[-2], wf.shape[-1]
+    bits = _bits(quant_type)
+    q = np.zeros(wf.shape[:-1] + (cols * bits // 8,), np.int8)
+    scales = np.empty(wf.shape[:-2] + (cols,), np.float32)
+    lib().orc_symmetric_quantize(_p(wf), _p(q), _p(scales), _sz(experts), _sz(rows), _sz(cols), _i(quant_type))
+    return q, torch.from_numpy(scales).to(weight.dtype)
+
+
+# ----------------------------------------------------------------------------- dequant + WOQ matmul
+def dequant_fma(q, scale, zero, group_size):
+    """Single-rounding dequantised weights (the bit-exact gate; oracle.c orc_dequant_fma).
+    q: numpy int8 [K, N]; scale/zero: torch 16-bit [K/g, N] (or [N] per-channel).  -> torch [K, N]."""
+    return _dequant("orc_dequant_fma", q, scale, zero, group_size)
+
+
+def dequant_torch(q, scale, zero, group_size):
+    """Two-rounding form used by the torch test reference
+    (test_weight_only_groupwise_quant_matmul.py:190-195)."""
+    return _dequant("orc_dequant_torch", q, scale, zero, group_size)
+
+
+def _dequant(fn, q, scale, zero, group_size):
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    K, N = q.shape
+    dt = scale.dtype
+    sc = _bits16(scale.reshape(-1, N))
+    zr = _bits16(zero.reshape(-1, N)) if zero is not None and zero.numel() else None
+    out = np.empty((K, N), np.uint16)
+    getattr(lib(), fn)(_p(q), _p(sc), _p(zr) if zr is not None else None, _p(out), _sz(K), _sz(N),
+                       _sz(group_size), _i(torch_dtype_code(dt)))
+    return _from_bits16(out, dt).reshape(K, N)
+
+
+def apply_per_channel_scale(act, pre_quant_scale):
+    """kernels/preQuantScaleKernel.cu:26-90 == torch.mul in the activation dtype."""
+    return (act * pre_quant_scale.reshape(1, -1).to(act.dtype))
+
+
+def matmul_16(a, w):
+    """fp64-accumulated A @ W on exactly widened 16-bit inputs -> torch fp32 [M, N]."""
+    M, K = a.shape
+    N = w.shape[1]
+    out = np.empty((M, N), np.float32)
+    lib().orc_matmul_16(_p(_bits16(a)), _p(_bits16(w)), _p(out), _sz(M), _sz(N), _sz(K),
+                        _i(torch_dtype_code(a.dtype)))
+    return torch.from_numpy(out)
+
+
+def woq_groupwise_matmul(act, pre_quant_scale, q_unpacked, scale, zero, bias, group_size, dequant="fma"):
+    """Reference result of WeightOnlyGroupwiseQuantMatmul (test_weight_only_groupwise_quant_matmul.py
+    :186-210, _utils.py:63-67): (act * pre) @ (q*scale + zero) + bias, output in the act dtype.
+    Returns (out16, out_f32_before_cast)."""
+    w = (dequant_fma if dequant == "fma" else dequant_torch)(q_unpacked, scale, zero, group_size)
+    a = act if pre_quant_scale is None else apply_per_channel_scale(act, pre_quant_scale)
+    ref = matmul_16(a.reshape(-1, a.shape[-1]), w)
+    if bias is not None and bias.numel():
+        ref = ref + bias.float().reshape(1, -1)
+    return ref.to(act.dtype), ref
+
+
+def woq_matmul(act, q_unpacked, scale):
+    """WeightOnlyQuantMatmul per-channel reference (test_weight_only_quant_matmul.py:99-119,
+    _utils.py:70-96): (act.float() @ q.float()) * scale, cast to the act dtype."""
+    K, N = q_unpacked.shape
+    qf = torch.from_numpy(np.ascontiguousarray(q_unpacked)).double()
+    ref = (act.reshape(-1, K).double() @ qf).float() * scale.float().reshape(1, -1)
+    return ref.to(act.dtype), ref
+
+
+def woq_tolerance(ref, wtype, dtype=None):
+    """_utils.py:99-109: atol = max|ref| * 2^-(bits-1) * 1.5 (x3 for bf16 in
+    cpp/tests/kernels/weightOnly/weightOnlyKernelTest.cpp:316-328)."""
+    bits = 8 if wtype == INT8_W else 4
+    atol = ref.float().abs().max().item() / (1 << (bits - 1)) * 1.5
+    return atol * (3.0 if dtype == torch.bfloat16 else 1.0)
+
+
+# ----------------------------------------------------------------------------- SmoothQuant
+def gemm_s8s8s32(a, b):
+    """int32 accumulators of A[M,K] x B[N,K]^T (exact).  numpy int8 in, int32 out."""
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    b = np.ascontiguousarray(b, dtype=np.int8)
+    M, K = a.shape
+    N = b.shape[0]
+    out = np.empty((M, N), np.int32)
+    lib().orc_gemm_s8s8s32(_p(a), _p(b), _p(out), _sz(M), _sz(N), _sz(K))
+    return out
+
+
+def smooth_quant_gemm(a, b, scale_tokens, scale_channels, per_token, per_channel, out_dtype):
+    """tests/quantization/_utils.py:112-142 with the kernel's epilogue order acc * (s_col * s_row)
+    (epilogue_per_row_per_col_scale.h:320-347).  out_dtype: torch.float16/float32/int32.
+    Returns (out, int32 accumulators)."""
+    acc = gemm_s8s8s32(a, b)
+    M, N = acc.shape
+    st = np.ascontiguousarray(scale_tokens.reshape(-1), np.float32)
+    sc = np.ascontiguousarray(scale_channels.reshape(-1), np.float32)
+    f = np.empty((M, N), np.float32)
+    lib().orc_sq_epilogue(_p(acc), _p(st), _p(sc), _p(f), _sz(M), _sz(N), _i(int(per_token)), _i(int(per_channel)))
+    t = torch.from_numpy(f)
+    if out_dtype == torch.int32:
+        t = torch.round(t).to(torch.int32)  # _utils.py:132-134 (rint == torch.round: half-to-even)
+    else:
+        t = t.to(out_dtype)
+    return t, acc
+
+
+def quantize_per_token(x):
+    """kernels/quantization.cu:93-127, _utils.py:145-150.  x torch [M, K] fp16/bf16/fp32."""
+    floor = torch.tensor(1e-6, dtype=x.dtype).float().item()
+    xf = x.float().contiguous().numpy()
+    M, K = xf.shape
+    q = np.empty((M, K), np.int8)
+    s = np.empty((M,), np.float32)
+    lib().orc_quantize_per_token(_p(xf), _p(q), _p(s), _sz(M), _sz(K), _c.c_float(floor))
+    return q, s.reshape(M, 1)
+
+
+# ----------------------------------------------------------------------------- FP8 e4m3 scales
+FP8_E4M3_MAX = 448.0
+
+
+def fp8_scale(amax):
+    """cpp/tensorrt_llm/common/cudaFp8Utils.cu:215-341: scale = max(amax / 448, 1 / (448 * 512))."""
+    return np.maximum(np.asarray(amax, np.float32) / np.float32(FP8_E4M3_MAX),
+                      np.float32(1.0 / (FP8_E4M3_MAX * 512.0)))
+
+
+def quantize_e4m3(x, mode):
+    """tests/quantization/test_fp8_quantization.py:37-120.  mode in {"activation" (per row),
+    "weight" (per column), "per_tensor"}.  Returns (fp8 tensor, fp32 scale)."""
+    xf = x.float()
+    if mode == "activation":
+        amax = xf.abs().amax(dim=-1, keepdim=True)
+    elif mode == "weight":
+        amax = xf.abs().amax(dim=0, keepdim=True)
+    else:
+        amax = xf.abs().amax().reshape(1, 1)
+    scale = torch.from_numpy(fp8_scale(amax.numpy()))
+    q = (xf / scale).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def fp8_gemm(a_fp8, b_fp8, scale_a, scale_b, out_dtype):
+    """Semantic restated from quantization/layers.py:777-879 (Q/DQ + matmul; the arithmetic itself
+    lives in closed libraries => PARITY UNPINNED): out = (a . b^T) * (s_a * s_b), fp32 accumulate.
+    a_fp8 [M,K], b_fp8 [N,K]."""
+    acc = a_fp8.float().double() @ b_fp8.float().double().t()
+    return (acc.float() * (float(scale_a) * float(scale_b))).to(out_dtype), acc.float()
+
+
+# ----------------------------------------------------------------------------- decode attention
+def rope_coefficients(pos, rot_dim, base=10000.0, scale=1.0):
+    """decoderMaskedMultiheadAttentionUtils.h:2581-2586: angle_i = pos*scale / base^(2i/rot_dim)."""
+    i = np.arange(0, rot_dim, 2, dtype=np.float32)
+    inv = np.float32(pos * scale) / np.power(np.float32(base), i / np.float32(rot_dim))
+    return np.cos(inv).astype(np.float32), np.sin(inv).astype(np.float32)
+
+
+def apply_rope(x, pos, rot_dim, kind, base=10000.0, scale=1.0):
+    """x: float32 numpy [Dh] already widened from T; returns float32 (caller rounds to T like
+    rotary_embedding_transform does, Utils.h:2596-2610).  kind: 'neox' pairs (i, i+rot/2)
+    (Template.h:1651-1711), 'gptj' pairs (2i, 2i+1) (:1637-1650)."""
+    c, s = rope_coefficients(pos, rot_dim, base, scale)
+    y = x.copy()
+    h = rot_dim // 2
+    if kind == "neox":
+        a, b = x[:h], x[h:rot_dim]
+        y[:h] = c * a - s * b
+        y[h:rot_dim] = c * b + s * a
+    elif kind == "gptj":
+        a, b = x[0:rot_dim:2], x[1:rot_dim:2]
+        y[0:rot_dim:2] = c * a - s * b
+        y[1:rot_dim:2] = c * b + s * a
+    return y
+
+
+class PagedKVCache:
+    """KVBlockArray layout (kernels/kvCacheUtils.h:36-153): pool of blocks, each
+    [2(K,V)][Hkv][tokens_per_block][Dh] like the test pool (test_gpt_attention.py:685-690); the
+    table is [B, 2, max_blocks] of block *addresses* (here: element offsets into `pool`; the GPU
+    harness turns them into device pointers)."""
+
+    def __init__(self, batch, num_kv_heads, head_dim, max_seq, tokens_per_block, dtype, seed=42):
+        assert tokens_per_block & (tokens_per_block - 1) == 0
+        self.B, self.H, self.D, self.tpb = batch, num_kv_heads, head_dim, tokens_per_block
+        self.max_blocks = (max_seq + tokens_per_block - 1) // tokens_per_block
+        nblk = batch * self.max_blocks
+        self.dtype = dtype
+        g = torch.Generator().manual_seed(seed)
+        perm = torch.randperm(nblk, generator=g)
+        self.block_ids = perm.reshape(batch, self.max_blocks)  # same block id for K and V halves
+        self.pool = torch.zeros(nblk, 2, num_kv_heads, tokens_per_block, head_dim, dtype=dtype)
+
+    def block_elems(self):
+        return self.H * self.tpb * self.D
+
+    def offsets(self):
+        """[B, 2, max_blocks] int64 element offsets of each K / V block inside pool.view(-1)."""
+        be = self.block_elems()
+        k = self.block_ids * (2 * be)
+        return torch.stack([k, k + be], dim=1).contiguous()
+
+    def write(self, b, kv, head, tok, vec):
+        self.pool[self.block_ids[b, tok // self.tpb], kv, head, tok % self.tpb] = vec
+
+    def gather(self, b, kv, head, length):
+        nb = (length + self.tpb - 1) // self.tpb
+        x = self.pool[self.block_ids[b, :nb], kv, head]  # [nb, tpb, D]
+        return x.reshape(nb * self.tpb, self.D)[:length]
+
+
+def quantize_kv(x, kv_dtype, scale_orig_quant):
+    """Cache-write quantisation.  int8: cvt.rni.sat.s8.f32(x * s)
+    (decoderMaskedMultiheadAttentionUtils.h:3629-3639, 3742-3749); fp8: e4m3 RNE of x * s."""
+    xf = x.float() * scale_orig_quant
+    if kv_dtype == torch.int8:
+        return torch.clamp(torch.round(xf), -128, 127).to(torch.int8)
+    if kv_dtype == torch.float8_e4m3fn:
+        return xf.to(torch.float8_e4m3fn)
+    return x.to(kv_dtype)
+
+
+def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_scaling=1.0, rope=None,
+                     rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None, kv_scale_orig_quant=1.0,
+                     kv_scale_quant_orig=1.0, update_cache=True):
+    """One generation step of GPTAttention over a paged cache, restating the MMHA math
+    (decoderMaskedMultiheadAttentionTemplate.h; conventions pinned by test_gpt_attention.py:1018,1154):
+      * seq_lens[b] INCLUDES the current token; tlength = seq_lens[b]-1 cached tokens (:1480-1482)
+      * q = qkv[:, :Hq*Dh], k = next Hkv*Dh, v = last Hkv*Dh (gptAttentionCommon.cpp:271-306)
+      * bias add, then RoPE at position tlength, results rounded to T (:1602-1711)
+      * logits = (q.k) * 1/(sqrt(Dh)*q_scaling) in fp32 (:1797, :2026)
+      * p = exp(l - max); out = sum p v / (sum p + 1e-6)  (:2259-2290)
+      * the current token uses its un-quantised k/v (registers), cached tokens are dequantised as
+        float(k8) * kv_scale_quant_orig (:1999-2003); new k/v are appended at position tlength.
+    fp32 everywhere else (the reference rounds P to T before P.V and reduces through T -- tolerance
+    parity only, test atol 2e-3, test_gpt_attention.py:1290-1293).
+    qkv: torch [B, (Hq+2Hkv)*Dh] in T.  Returns out torch [B, Hq*Dh] in T."""
+    T = qkv.dtype
+    B = qkv.shape[0]
+    Hq, Hkv, D = num_heads, num_kv_heads, head_dim
+    inv_sqrt = 1.0 / (math.sqrt(D) * q_scaling)
+    x = qkv.float()
+    if qkv_bias is not None:
+        x = (qkv + qkv_bias.reshape(1, -1).to(T)).float()  # add in T (Template.h:1602-1606)
+    out = torch.zeros(B, Hq * D, dtype=torch.float32)
+    grp = Hq // Hkv
+    for b in range(B):
+        tl = int(seq_lens[b]) - 1
+        q = x[b, :Hq * D].reshape(Hq, D).numpy().copy()
+        k = x[b, Hq * D:(Hq + Hkv) * D].reshape(Hkv, D).numpy().copy()
+        v = x[b, (Hq + Hkv) * D:].reshape(Hkv, D).numpy().copy()
+        if rope is not None:
+            for h in range(Hq):
+                q[h] = apply_rope(q[h], tl, rot_dim, rope, rope_base, rope_scale)
+            for h in range(Hkv):
+                k[h] = apply_rope(k[h], tl, rot_dim, rope, rope_base, rope_scale)
+            q = torch.from_numpy(q).to(T).float().numpy()
+            k = torch.from_numpy(k).to(T).float().numpy()
+        for hk in range(Hkv):
+            kc = cache.gather(b, 0, hk, tl).float() * kv_scale_quant_orig
+            vc = cache.gather(b, 1, hk, tl).float() * kv_scale_quant_orig
+            kk = torch.cat([kc, torch.from_numpy(k[hk:hk + 1])], 0).double()
+            vv = torch.cat([vc, torch.from_numpy(v[hk:hk + 1])], 0).double()
+            for g in range(grp):
+                h = hk * grp + g
+                logits = (kk @ torch.from_numpy(q[h]).double()).float() * np.float32(inv_sqrt)
+                p = torch.exp(logits - logits.max())
+                o = (p.double() @ vv).float() / (p.sum() + 1e-6)
+                out[b, h * D:(h + 1) * D] = o
+            if update_cache:
+                cache.write(b, 0, hk, tl, quantize_kv(torch.from_numpy(k[hk]).to(T), cache.dtype, kv_scale_orig_quant))
+                cache.write(b, 1, hk, tl, quantize_kv(torch.from_numpy(v[hk]).to(T), cache.dtype, kv_scale_orig_quant))
+    return out.to(T)

@@ -1,0 +1,680 @@
+// decode_attn.hip -- one generation step of masked multi-head / grouped-query attention over the
+// KVBlockArray paged cache (replaces kernels/decoderMaskedMultiheadAttention/* and the XQA cubins,
+// reference: decoderMaskedMultiheadAttentionTemplate.h:1303-2800, kvCacheUtils.h:36-153).
+//
+// Design (gfx950, HBM-bound):
+//   * one workgroup = (sequence b, kv head hk, kv split s), 4 waves; ALL q heads of the kv group are
+//     served by the same K/V stream (XQA-style), so the cache is read exactly once.
+//   * K/V rows go straight to VGPRs with 16-byte-per-lane loads: LPT = Dh*elem/16 lanes cover one
+//     token row, one wave-instruction reads TPW = 64/LPT consecutive tokens = 1 KiB contiguous
+//     (tokens of one head are contiguous inside a block: [Hkv][tokens_per_block][Dh]).
+//   * q.k partial dots use v_dot2c_f32_{bf16,f16}; the LPT-lane reduction uses DPP only.
+//   * every (wave, token slot) keeps an independent online-softmax state (m, l, acc) so the K/V
+//     loop has no cross-lane traffic besides the dot reduction; states are merged once at the end
+//     (in-wave shuffles, then LDS across waves, then -- for multi-block -- a tiny merge kernel that
+//     keeps partials in fp32).
+//   * the new token's bias + RoPE + cache append (quantised for int8/fp8 caches) is fused in.
+#include "kernels.h"
+#include <cfloat>
+
+namespace mi355q
+{
+
+namespace
+{
+
+constexpr int NW = 4; // waves per workgroup
+constexpr float NEG_BIG = -1e30f;
+
+struct DecodeArgs
+{
+    const void* qkv;
+    const void* qkv_bias;
+    void* out;
+    const int32_t* seq_lens;
+    const int64_t* block_ptrs;
+    const float* kv_scale_orig_quant;
+    const float* kv_scale_quant_orig;
+    float* part_acc; // [B, Hq, splits, DH]
+    float* part_ml;  // [B, Hq, splits, 2]
+    int batch, num_heads, num_kv_heads;
+    int max_blocks, tpb_log2;
+    int splits;
+    int pos_type, rot_dim, rot_scale_type, rot_max_pos;
+    float rot_base, rot_scale;
+    float score_scale; // 1 / (sqrt(Dh) * q_scaling)
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+template <typename T>
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c);
+template <>
+__device__ __forceinline__ float dot2<bf16_t>(uint32_t a, uint32_t b, float c)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+template <>
+__device__ __forceinline__ float dot2<f16_t>(uint32_t a, uint32_t b, float c)
+{
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+}
+
+// sum over the LPT lanes that hold one token row; every lane of the group ends with the total.
+template <int LPT>
+__device__ __forceinline__ float group_sum(float v)
+{
+#define MQ_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    if (LPT >= 2)
+        MQ_DPP_ADD(0xB1); // quad_perm [1,0,3,2]
+    if (LPT >= 4)
+        MQ_DPP_ADD(0x4E); // quad_perm [2,3,0,1]
+    if (LPT >= 8)
+        MQ_DPP_ADD(0x141); // row_half_mirror
+    if (LPT >= 16)
+        MQ_DPP_ADD(0x140); // row_mirror
+#undef MQ_DPP_ADD
+    if (LPT >= 32)
+        v += __shfl_xor(v, 16);
+    if (LPT >= 64)
+        v += __shfl_xor(v, 32);
+    return v;
+}
+
+// KVT: 0 = cache holds T, 1 = int8, 2 = fp8 e4m3 (OCP)
+template <int KVT>
+__device__ __forceinline__ float kv8_to_float(uint32_t w, int byte);
+template <>
+__device__ __forceinline__ float kv8_to_float<1>(uint32_t w, int byte)
+{
+    return (float) (int8_t) (w >> (8 * byte));
+}
+template <>
+__device__ __forceinline__ float kv8_to_float<2>(uint32_t w, int byte)
+{
+    switch (byte)
+    {
+    case 0: return __builtin_amdgcn_cvt_f32_fp8((int) w, 0);
+    case 1: return __builtin_amdgcn_cvt_f32_fp8((int) w, 1);
+    case 2: return __builtin_amdgcn_cvt_f32_fp8((int) w, 2);
+    default: return __builtin_amdgcn_cvt_f32_fp8((int) w, 3);
+    }
+}
+
+__device__ __forceinline__ uint8_t float_to_int8_sat(float x)
+{
+    // cvt.rni.sat.s8.f32 (decoderMaskedMultiheadAttentionUtils.h:3629-3639)
+    float r = rintf(x);
+    r = fminf(fmaxf(r, -128.f), 127.f);
+    return (uint8_t) (int8_t) (int) r;
+}
+
+__device__ __forceinline__ uint8_t float_to_fp8(float x)
+{
+    // OCP e4m3fn, RNE, saturating to +-448 like __nv_fp8_e4m3's default conversion
+    x = fminf(fmaxf(x, -448.f), 448.f);
+    return (uint8_t) (__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
+}
+
+template <typename T, int KVT, int DH, int G, int U>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
+{
+    constexpr int KVB = KVT == 0 ? 2 : 1;  // bytes per cache element
+    constexpr int E = 16 / KVB;            // cache elements per lane per load
+    constexpr int LPT = DH / E;            // lanes per token row
+    constexpr int TPW = 64 / LPT;          // token rows per wave-load
+    constexpr int TILE = TPW * U;          // tokens per wave iteration
+    constexpr int EP = E / 2;              // packed 16-bit pairs per lane
+    static_assert(DH % E == 0 && LPT <= 64 && LPT >= 2, "unsupported head size");
+
+    // LDS: phase 1 holds q (G heads), k, v of the new token as floats already rounded to T;
+    //      phase 2 (after the loop) holds the per-wave partial states.
+    constexpr int RED_FLOATS = NW * G * (DH + 2);
+    constexpr int QKV_FLOATS = (G + 2) * DH;
+    __shared__ float smem[RED_FLOATS > QKV_FLOATS ? RED_FLOATS : QKV_FLOATS];
+    float* q_s = smem;              // [G][DH]
+    float* k_s = smem + G * DH;     // [DH]
+    float* v_s = k_s + DH;          // [DH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x % p.splits;
+    const int bh = blockIdx.x / p.splits;
+    const int hk = bh % p.num_kv_heads;
+    const int b = bh / p.num_kv_heads;
+    const int Hq = p.num_heads, Hkv = p.num_kv_heads;
+    const int tl = p.seq_lens[b] - 1; // cached tokens; the current token sits at position tl
+    const int tpb = 1 << p.tpb_log2;
+    const bool last_split = split == p.splits - 1;
+
+    // ---- stage q (G heads), k, v of the new token: bias add in T, RoPE in fp32, round to T
+    {
+        const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * DH;
+        const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.qkv_bias);
+        for (int i = tid; i < (G + 2) * DH; i += NW * 64)
+        {
+            int vec = i / DH, d = i % DH;
+            int off = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
+            float x = T16<T>::to_float(qkv[off]);
+            if (bias)
+                x = T16<T>::to_float(T16<T>::from_float(x + T16<T>::to_float(bias[off])));
+            smem[i] = x;
+        }
+        __syncthreads();
+        if (p.pos_type == 1 || p.pos_type == 2) // kROPE_GPTJ / kROPE_GPT_NEOX
+        {
+            const int half = p.rot_dim >> 1;
+            float base = p.rot_base, scale = p.rot_scale;
+            // update_rotary_base_n_scale (decoderMaskedMultiheadAttentionUtils.h:2552-2579)
+            if (p.rot_scale_type == 2)
+            {
+                if (tl > p.rot_max_pos)
+                {
+                    float bb = tl * (scale / p.rot_max_pos) - (scale - 1.f);
+                    base = base * powf(bb, (float) p.rot_dim / (float) (p.rot_dim - 2));
+                }
+                scale = 1.f;
+            }
+            else if (p.rot_scale_type == 1)
+                scale = 1.f / scale;
+            for (int i = tid; i < (G + 1) * half; i += NW * 64)
+            {
+                int vec = i / half, j = i % half;
+                float* x = smem + vec * DH;
+                int i0 = p.pos_type == 2 ? j : 2 * j;
+                int i1 = p.pos_type == 2 ? j + half : 2 * j + 1;
+                float ang = ((float) tl * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
+                float sn, cs;
+                sincosf(ang, &sn, &cs);
+                float a = x[i0], c = x[i1];
+                x[i0] = T16<T>::to_float(T16<T>::from_float(cs * a - sn * c));
+                x[i1] = T16<T>::to_float(T16<T>::from_float(cs * c + sn * a));
+            }
+            __syncthreads();
+        }
+    }
+
+    const int ts = lane / LPT;  // token slot inside a wave-load
+    const int ch = lane % LPT;  // 16-byte chunk of the row
+    const float k_deq = KVT ? p.kv_scale_quant_orig[0] : 1.f;
+
+    // q chunk of this lane, packed 16-bit pairs (exact: q was rounded to T above)
+    uint32_t qp[G][EP];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < EP; ++e)
+            qp[g][e] = pack2<T>(q_s[g * DH + ch * E + 2 * e], q_s[g * DH + ch * E + 2 * e + 1]);
+
+    float m[G], l[G], acc[G][E];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+    {
+        m[g] = NEG_BIG;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            acc[g][e] = 0.f;
+    }
+    // logits are kept in the log2 domain: exp(x) = exp2(x * log2(e))
+    const float sscale = p.score_scale * 1.4426950408889634f * k_deq;
+
+    // ---- the new token (registers, un-quantised), handled by wave 0 / slot 0 of the last split
+    if (last_split && wave == 0 && ts == 0)
+    {
+        float kf[E], vf[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+        {
+            kf[e] = k_s[ch * E + e];
+            vf[e] = v_s[ch * E + e];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EP; ++e)
+                s = dot2<T>(qp[g][e], pack2<T>(kf[2 * e], kf[2 * e + 1]), s);
+            s = group_sum<LPT>(s) * (p.score_scale * 1.4426950408889634f);
+            m[g] = s;
+            l[g] = 1.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                acc[g][e] = vf[e];
+        }
+        // append to the cache at position tl (cyclic/sink addressing not enabled: identity map)
+        const int64_t* bp = p.block_ptrs + (size_t) b * 2 * p.max_blocks;
+        const int blk = tl >> p.tpb_log2;
+        const size_t row = ((size_t) hk * tpb + (tl & (tpb - 1))) * DH * KVB + (size_t) ch * 16;
+        uint4 kw, vw;
+        if constexpr (KVT == 0)
+        {
+            uint32_t* kk = reinterpret_cast<uint32_t*>(&kw);
+            uint32_t* vv = reinterpret_cast<uint32_t*>(&vw);
+#pragma unroll
+            for (int e = 0; e < EP; ++e)
+            {
+                kk[e] = pack2<T>(kf[2 * e], kf[2 * e + 1]);
+                vv[e] = pack2<T>(vf[2 * e], vf[2 * e + 1]);
+            }
+        }
+        else
+        {
+            const float qs = p.kv_scale_orig_quant[0];
+            uint8_t* kk = reinterpret_cast<uint8_t*>(&kw);
+            uint8_t* vv = reinterpret_cast<uint8_t*>(&vw);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+            {
+                kk[e] = KVT == 1 ? float_to_int8_sat(kf[e] * qs) : float_to_fp8(kf[e] * qs);
+                vv[e] = KVT == 1 ? float_to_int8_sat(vf[e] * qs) : float_to_fp8(vf[e] * qs);
+            }
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(bp[blk]) + row) = kw;
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(bp[p.max_blocks + blk]) + row) = vw;
+    }
+
+    // ---- stream the cached tokens of this split
+    {
+        const int ntiles = (tl + TILE - 1) / TILE;
+        const int tps = (ntiles + p.splits - 1) / p.splits;
+        const int tile_end = min(ntiles, (split + 1) * tps);
+        const int64_t* bp = p.block_ptrs + (size_t) b * 2 * p.max_blocks;
+        const size_t head_off = (size_t) hk * tpb * DH * KVB + (size_t) ch * 16;
+
+        for (int tile = split * tps + wave; tile < tile_end; tile += NW)
+        {
+            const int t0 = tile * TILE;
+            const int blk = t0 >> p.tpb_log2;
+            const char* kbase = reinterpret_cast<const char*>(bp[blk]) + head_off;
+            const char* vbase = reinterpret_cast<const char*>(bp[p.max_blocks + blk]) + head_off;
+            const int tin = (t0 & (tpb - 1)) + ts;
+
+            uint4 kreg[U], vreg[U];
+            bool valid[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                valid[u] = t0 + u * TPW + ts < tl;
+                kreg[u] = make_uint4(0, 0, 0, 0);
+                if (valid[u])
+                    kreg[u] = *reinterpret_cast<const uint4*>(kbase + (size_t) (tin + u * TPW) * DH * KVB);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                vreg[u] = make_uint4(0, 0, 0, 0);
+                if (valid[u])
+                    vreg[u] = *reinterpret_cast<const uint4*>(vbase + (size_t) (tin + u * TPW) * DH * KVB);
+            }
+
+            float s[G][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                uint32_t kp[EP];
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(&kreg[u]);
+                if constexpr (KVT == 0)
+                {
+#pragma unroll
+                    for (int e = 0; e < EP; ++e)
+                        kp[e] = w[e];
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < EP; ++e) // 8-bit values are exact in fp16 and in bf16
+                        kp[e] = pack2<T>(kv8_to_float<KVT>(w[e / 2], (2 * e) & 3),
+                            kv8_to_float<KVT>(w[e / 2], (2 * e + 1) & 3));
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                {
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EP; ++e)
+                        d = dot2<T>(qp[g][e], kp[e], d);
+                    s[g][u] = group_sum<LPT>(d) * sscale;
+                }
+            }
+
+            float pr[G][U];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+            {
+                float mx = m[g];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    mx = valid[u] ? fmaxf(mx, s[g][u]) : mx;
+                const float corr = __builtin_amdgcn_exp2f(m[g] - mx);
+                m[g] = mx;
+                float ps = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    pr[g][u] = valid[u] ? __builtin_amdgcn_exp2f(s[g][u] - mx) : 0.f;
+                    ps += pr[g][u];
+                }
+                l[g] = l[g] * corr + ps;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    acc[g][e] *= corr;
+            }
+
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                float vf[E];
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(&vreg[u]);
+                if constexpr (KVT == 0)
+                {
+#pragma unroll
+                    for (int e = 0; e < EP; ++e)
+                    {
+                        vf[2 * e] = T16<T>::lo(w[e]);
+                        vf[2 * e + 1] = T16<T>::hi(w[e]);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        vf[e] = kv8_to_float<KVT>(w[e / 4], e & 3);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                {
+                    // cached V of an 8-bit cache is dequantised as float(v8) * kv_scale_quant_orig
+                    const float pv = KVT ? pr[g][u] * k_deq : pr[g][u];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        acc[g][e] = fmaf(pv, vf[e], acc[g][e]);
+                }
+            }
+        }
+    }
+
+    // ---- merge the TPW token slots of the wave (lanes with equal `ch`)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+    {
+        float mw = m[g];
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1)
+            mw = fmaxf(mw, __shfl_xor(mw, o));
+        const float c = __builtin_amdgcn_exp2f(m[g] - mw);
+        l[g] *= c;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            acc[g][e] *= c;
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1)
+        {
+            l[g] += __shfl_xor(l[g], o);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                acc[g][e] += __shfl_xor(acc[g][e], o);
+        }
+        m[g] = mw;
+    }
+
+    // ---- merge the waves through LDS
+    __syncthreads(); // everyone is done with q_s/k_s/v_s
+    float* red = smem; // [NW][G][DH + 2]
+    if (ts == 0)
+    {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+        {
+            float* r = red + (wave * G + g) * (DH + 2);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                r[ch * E + e] = acc[g][e];
+            if (ch == 0)
+            {
+                r[DH] = m[g];
+                r[DH + 1] = l[g];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < G * DH; i += NW * 64)
+    {
+        const int g = i / DH, d = i % DH;
+        float mm = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            mm = fmaxf(mm, red[(w * G + g) * (DH + 2) + DH]);
+        float ll = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+        {
+            const float* r = red + (w * G + g) * (DH + 2);
+            const float c = __builtin_amdgcn_exp2f(r[DH] - mm);
+            ll += r[DH + 1] * c;
+            o += r[d] * c;
+        }
+        const int h = hk * G + g;
+        if (p.splits == 1)
+        {
+            // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2285-2290)
+            const float r = o / (ll + 1e-6f);
+            reinterpret_cast<uint16_t*>(p.out)[((size_t) b * Hq + h) * DH + d] = T16<T>::from_float(r);
+        }
+        else
+        {
+            const size_t pi = ((size_t) b * Hq + h) * p.splits + split;
+            p.part_acc[pi * DH + d] = o;
+            if (d == 0)
+            {
+                p.part_ml[pi * 2] = mm;
+                p.part_ml[pi * 2 + 1] = ll;
+            }
+        }
+    }
+}
+
+// multi-block merge (reference: decoderMaskedMultiheadAttentionTemplate.h:2634-2786, but partials
+// stay fp32 here).  grid = B*Hq, block = DH.
+template <typename T>
+__global__ void decode_attn_merge_kernel(
+    const float* part_acc, const float* part_ml, void* out, int splits, int dh)
+{
+    const size_t bh = blockIdx.x;
+    const int d = threadIdx.x;
+    float mm = NEG_BIG;
+    for (int s = 0; s < splits; ++s)
+        mm = fmaxf(mm, part_ml[(bh * splits + s) * 2]);
+    float ll = 0.f, o = 0.f;
+    for (int s = 0; s < splits; ++s)
+    {
+        const float c = __builtin_amdgcn_exp2f(part_ml[(bh * splits + s) * 2] - mm);
+        ll += part_ml[(bh * splits + s) * 2 + 1] * c;
+        o += part_acc[(bh * splits + s) * dh + d] * c;
+    }
+    reinterpret_cast<uint16_t*>(out)[bh * dh + d] = T16<T>::from_float(o / (ll + 1e-6f));
+}
+
+int ilog2(int x)
+{
+    int l = 0;
+    while ((1 << l) < x)
+        ++l;
+    return l;
+}
+
+int choose_splits(const mi355q_decode_attention_params& q, int tile)
+{
+    if (q.multi_block_mode > 0)
+        return q.multi_block_mode;
+    const int wgs = q.batch * q.num_kv_heads;
+    const int max_tiles = (q.max_seq_len + tile - 1) / tile;
+    // aim for >= 4 workgroups per CU, never less than NW tiles per workgroup
+    int s = (1024 + wgs - 1) / wgs;
+    s = std::min(s, std::max(1, max_tiles / NW));
+    return std::max(1, std::min(s, 64));
+}
+
+template <int KVB>
+constexpr int tile_tokens(int dh, int u)
+{
+    return 64 / (dh / (16 / KVB)) * u;
+}
+
+int pick_unroll(int dh, int kvb, int tpb, int g)
+{
+    const int tpw = 64 / (dh / (16 / kvb));
+    int u = g >= 8 ? 2 : (g >= 4 ? 4 : 8); // bound the G x U score registers
+    while (u > 1 && tpw * u > tpb)
+        u >>= 1;
+    return u;
+}
+
+template <typename T, int KVT, int DH, int G, int U>
+void launch(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStream_t stream)
+{
+    const int grid = q.batch * q.num_kv_heads * a.splits;
+    hipLaunchKernelGGL((decode_attn_kernel<T, KVT, DH, G, U>), dim3(grid), dim3(NW * 64), 0, stream, a);
+    if (a.splits > 1)
+        hipLaunchKernelGGL((decode_attn_merge_kernel<T>), dim3(q.batch * q.num_heads), dim3(DH), 0, stream,
+            a.part_acc, a.part_ml, q.out, a.splits, DH);
+}
+
+template <typename T, int KVT, int DH, int G>
+void dispatch_u(const mi355q_decode_attention_params& q, const DecodeArgs& a, int u, hipStream_t s)
+{
+    switch (u)
+    {
+    case 8: launch<T, KVT, DH, G, 8>(q, a, s); break;
+    case 4: launch<T, KVT, DH, G, 4>(q, a, s); break;
+    case 2: launch<T, KVT, DH, G, 2>(q, a, s); break;
+    default: launch<T, KVT, DH, G, 1>(q, a, s); break;
+    }
+}
+
+template <typename T, int KVT, int DH>
+void dispatch_g(const mi355q_decode_attention_params& q, const DecodeArgs& a, int u, hipStream_t s)
+{
+    const int g = q.num_heads / q.num_kv_heads;
+    switch (g)
+    {
+    case 1: dispatch_u<T, KVT, DH, 1>(q, a, u, s); break;
+    case 2: dispatch_u<T, KVT, DH, 2>(q, a, u, s); break;
+    case 4: dispatch_u<T, KVT, DH, 4>(q, a, u, s); break;
+    case 8: dispatch_u<T, KVT, DH, 8>(q, a, u, s); break;
+    default: MQ_UNSUPPORTED("decode attention: q heads per kv head must be 1, 2, 4 or 8 (got %d)", g);
+    }
+}
+
+template <typename T, int KVT>
+void dispatch_dh(const mi355q_decode_attention_params& q, const DecodeArgs& a, int u, hipStream_t s)
+{
+    switch (q.head_size)
+    {
+    case 64: dispatch_g<T, KVT, 64>(q, a, u, s); break;
+    case 128: dispatch_g<T, KVT, 128>(q, a, u, s); break;
+    default: MQ_UNSUPPORTED("decode attention: head_size %d not built (64, 128)", q.head_size);
+    }
+}
+
+template <typename T>
+void dispatch_kv(const mi355q_decode_attention_params& q, const DecodeArgs& a, int u, hipStream_t s)
+{
+    if (q.kv_type == q.act_type)
+        dispatch_dh<T, 0>(q, a, u, s);
+    else if (q.kv_type == MI355Q_INT8)
+        dispatch_dh<T, 1>(q, a, u, s);
+    else if (q.kv_type == MI355Q_FP8)
+        dispatch_dh<T, 2>(q, a, u, s);
+    else
+        MQ_UNSUPPORTED("decode attention: kv cache type %d", q.kv_type);
+}
+
+struct Plan
+{
+    int kvb, u, tile, splits;
+};
+
+Plan make_plan(const mi355q_decode_attention_params& q)
+{
+    MQ_CHECK(q.act_type == MI355Q_HALF || q.act_type == MI355Q_BF16, "act_type %d", q.act_type);
+    MQ_CHECK(q.batch > 0 && q.num_heads > 0 && q.num_kv_heads > 0, "bad sizes");
+    MQ_CHECK(q.num_heads % q.num_kv_heads == 0, "num_heads %% num_kv_heads");
+    MQ_CHECK(q.tokens_per_block > 0 && (q.tokens_per_block & (q.tokens_per_block - 1)) == 0,
+        "tokens_per_block must be a power of 2 (kvCacheUtils.h:80-82), got %d", q.tokens_per_block);
+    MQ_CHECK(q.max_seq_len >= 1 && q.max_seq_len <= q.max_blocks_per_seq * q.tokens_per_block,
+        "max_seq_len %d exceeds the block table (%d x %d)", q.max_seq_len, q.max_blocks_per_seq, q.tokens_per_block);
+    Plan pl;
+    pl.kvb = q.kv_type == q.act_type ? 2 : 1;
+    MQ_CHECK(q.head_size == 64 || q.head_size == 128, "head_size %d not built (64, 128)", q.head_size);
+    const int tpw = 64 / (q.head_size / (16 / pl.kvb));
+    MQ_CHECK(q.tokens_per_block >= tpw, "tokens_per_block %d < %d rows per wave-load", q.tokens_per_block, tpw);
+    pl.u = pick_unroll(q.head_size, pl.kvb, q.tokens_per_block, q.num_heads / q.num_kv_heads);
+    pl.tile = tpw * pl.u;
+    pl.splits = choose_splits(q, pl.tile);
+    return pl;
+}
+
+} // namespace
+
+size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
+{
+    make_plan(q);
+    // batch' * splits(batch') <= 1024 / Hkv + batch' for every batch' <= batch, so this bound holds
+    // for any smaller batch enqueued later (TensorRT asks once, at configure time, with max shapes)
+    size_t rows = q.multi_block_mode > 0 ? (size_t) q.batch * q.multi_block_mode
+                                         : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
+    return rows * q.num_heads * (q.head_size + 2) * sizeof(float);
+}
+
+void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream)
+{
+    Plan pl = make_plan(q);
+    MQ_CHECK(q.qkv && q.out && q.sequence_lengths && q.block_pointers, "null tensor");
+    if (pl.kvb == 1)
+        MQ_CHECK(q.kv_scale_orig_quant && q.kv_scale_quant_orig, "8-bit kv cache needs both scales");
+    DecodeArgs a{};
+    a.qkv = q.qkv;
+    a.qkv_bias = q.qkv_bias;
+    a.out = q.out;
+    a.seq_lens = q.sequence_lengths;
+    a.block_ptrs = q.block_pointers;
+    a.kv_scale_orig_quant = q.kv_scale_orig_quant;
+    a.kv_scale_quant_orig = q.kv_scale_quant_orig;
+    a.batch = q.batch;
+    a.num_heads = q.num_heads;
+    a.num_kv_heads = q.num_kv_heads;
+    a.max_blocks = q.max_blocks_per_seq;
+    a.tpb_log2 = ilog2(q.tokens_per_block);
+    a.splits = pl.splits;
+    a.pos_type = q.position_embedding_type;
+    a.rot_dim = q.rotary_embedding_dim;
+    a.rot_scale_type = q.rotary_embedding_scale_type;
+    a.rot_max_pos = q.rotary_embedding_max_positions;
+    a.rot_base = q.rotary_embedding_base;
+    a.rot_scale = q.rotary_embedding_scale;
+    a.score_scale = 1.f / (sqrtf((float) q.head_size) * (q.q_scaling == 0.f ? 1.f : q.q_scaling));
+    if (q.position_embedding_type == 1 || q.position_embedding_type == 2)
+        MQ_CHECK(q.rotary_embedding_dim > 0 && q.rotary_embedding_dim <= q.head_size && q.rotary_embedding_dim % 2 == 0,
+            "rotary_embedding_dim %d", q.rotary_embedding_dim);
+    else
+        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in decode (0,1,2)",
+            q.position_embedding_type);
+    if (pl.splits > 1)
+    {
+        const size_t need = (size_t) q.batch * q.num_heads * pl.splits * (q.head_size + 2) * sizeof(float);
+        MQ_CHECK(q.workspace && q.workspace_bytes >= need, "workspace too small: %zu < %zu", q.workspace_bytes, need);
+        a.part_acc = reinterpret_cast<float*>(q.workspace);
+        a.part_ml = a.part_acc + (size_t) q.batch * q.num_heads * pl.splits * q.head_size;
+    }
+    if (q.act_type == MI355Q_BF16)
+        dispatch_kv<bf16_t>(q, a, pl.u, stream);
+    else
+        dispatch_kv<f16_t>(q, a, pl.u, stream);
+    MQ_HIP(hipGetLastError());
+}
+
+} // namespace mi355q

@@ -1,0 +1,439 @@
+// gemm8.hip -- 8-bit "TN" GEMMs on the gfx950 matrix cores:
+//   * SmoothQuant W8A8: int8 x int8 -> int32 (v_mfma_i32_32x32x32_i8), fused
+//     per-token x per-channel fp32 dequant epilogue.  Replaces
+//     kernels/cutlass_kernels/int8_gemm/int8_gemm_template.h:62-172 and
+//     cutlass_extensions/epilogue/threadblock/epilogue_per_row_per_col_scale.h:279-347.
+//   * FP8 e4m3 (OCP) x e4m3 -> fp32 (v_mfma_f32_32x32x16_fp8_fp8) with per-tensor scales.
+//     Replaces the TensorRT Q/DQ fusion / cuBLASLt fp8 path (plugins/gemmPlugin/gemmPlugin.cpp:193-198).
+//   * per-token int8 quantisation (kernels/quantization.cu:93-127) and e4m3 quantisation
+//     (common/cudaFp8Utils.cu) feeder kernels.
+// A is [M, K] row-major, B is [N, K] row-major (smoothQuantGemmPlugin.cpp:224-230), so both MFMA
+// operands are K-contiguous: a lane's fragment is 16 (int8) or 8 (fp8) consecutive bytes of a row.
+#include "kernels.h"
+
+namespace mi355q
+{
+
+namespace
+{
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(16))) int i32x16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int BM = 128, BN = 128, BK = 64; // BK in bytes == elements
+constexpr int LDS_STRIDE = BK + 16;        // 80-byte rows: 16-B aligned, breaks the 64-B bank period
+
+struct Gemm8Args
+{
+    const uint8_t* A;
+    const uint8_t* B;
+    void* C;
+    const float* alpha_col; // per-channel [N] (or [1])
+    const float* alpha_row; // per-token   [M] (or [1])
+    int per_token, per_channel;
+    int m, n, k;
+    int out_type;
+};
+
+template <bool FP8>
+struct Acc;
+template <>
+struct Acc<false>
+{
+    typedef i32x16_t type;
+};
+template <>
+struct Acc<true>
+{
+    typedef f32x16_t type;
+};
+
+__device__ __forceinline__ void store_out(void* C, int out_type, size_t idx, float v)
+{
+    switch (out_type)
+    {
+    case MI355Q_HALF: reinterpret_cast<uint16_t*>(C)[idx] = float_to_f16_bits(v); break;
+    case MI355Q_BF16: reinterpret_cast<uint16_t*>(C)[idx] = float_to_bf16_bits(v); break;
+    case MI355Q_FLOAT: reinterpret_cast<float*>(C)[idx] = v; break;
+    default: reinterpret_cast<int32_t*>(C)[idx] = (int32_t) rintf(v); break; // round-to-nearest-even
+    }
+}
+
+// 128 x 128 output tile, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
+template <bool FP8>
+__global__ __launch_bounds__(256) void gemm8_kernel(Gemm8Args g)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sA[2][BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t sB[2][BN * LDS_STRIDE];
+    typedef typename Acc<FP8>::type acc_t;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+
+    // staging: tile = 128 rows x 64 B = 512 chunks of 16 B; thread handles chunks tid and tid + 256
+    const int srow = tid >> 2, scol = (tid & 3) * 16;
+
+    acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0;
+
+    uint4 ra[2], rb[2];
+    auto load_tiles = [&](int k0)
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+            const int r = srow + h * 64;
+            ra[h] = make_uint4(0, 0, 0, 0);
+            rb[h] = make_uint4(0, 0, 0, 0);
+            if (bm0 + r < g.m && k0 + scol < g.k)
+                ra[h] = *reinterpret_cast<const uint4*>(g.A + (size_t) (bm0 + r) * g.k + k0 + scol);
+            if (bn0 + r < g.n && k0 + scol < g.k)
+                rb[h] = *reinterpret_cast<const uint4*>(g.B + (size_t) (bn0 + r) * g.k + k0 + scol);
+        }
+    };
+    auto store_tiles = [&](int buf)
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+            const int r = srow + h * 64;
+            *reinterpret_cast<uint4*>(&sA[buf][r * LDS_STRIDE + scol]) = ra[h];
+            *reinterpret_cast<uint4*>(&sB[buf][r * LDS_STRIDE + scol]) = rb[h];
+        }
+    };
+
+    const int nk = (g.k + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt)
+    {
+        const int buf = kt & 1;
+        if (kt + 1 < nk)
+            load_tiles((kt + 1) * BK);
+
+        if constexpr (!FP8)
+        {
+            // v_mfma_i32_32x32x32_i8: lane l holds A[row l&31][k = 16*(l>>5) .. +15]
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks)
+            {
+                i32x4_t fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                {
+                    const int ar = wm * 64 + i * 32 + (lane & 31);
+                    const int br = wn * 64 + i * 32 + (lane & 31);
+                    const int kc = ks * 32 + (lane >> 5) * 16;
+                    fa[i] = *reinterpret_cast<const i32x4_t*>(&sA[buf][ar * LDS_STRIDE + kc]);
+                    fb[i] = *reinterpret_cast<const i32x4_t*>(&sB[buf][br * LDS_STRIDE + kc]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        else
+        {
+            // v_mfma_f32_32x32x16_fp8_fp8: lane l holds A[row l&31][k = 8*(l>>5) .. +7]
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks)
+            {
+                long fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                {
+                    const int ar = wm * 64 + i * 32 + (lane & 31);
+                    const int br = wn * 64 + i * 32 + (lane & 31);
+                    const int kc = ks * 16 + (lane >> 5) * 8;
+                    fa[i] = *reinterpret_cast<const long*>(&sA[buf][ar * LDS_STRIDE + kc]);
+                    fb[i] = *reinterpret_cast<const long*>(&sB[buf][br * LDS_STRIDE + kc]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+
+        if (kt + 1 < nk)
+        {
+            store_tiles(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // out = cvt(float(acc) * (scale_col * scale_row))  (epilogue_per_row_per_col_scale.h:320-347)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+        {
+            const int col = bn0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.n)
+                continue;
+            const float sc = g.alpha_col[g.per_channel ? col : 0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+            {
+                const int row = bm0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.m)
+                    continue;
+                const float sr = g.alpha_row[g.per_token ? row : 0];
+                store_out(g.C, g.out_type, (size_t) row * g.n + col, (float) acc[i][j][r] * (sc * sr));
+            }
+        }
+}
+
+// ---- per-token int8 quantisation: one wave per row (kernels/quantization.cu:93-127)
+template <typename T>
+__device__ __forceinline__ float load_as_float(const void* src, size_t i);
+template <>
+__device__ __forceinline__ float load_as_float<float>(const void* src, size_t i)
+{
+    return reinterpret_cast<const float*>(src)[i];
+}
+template <>
+__device__ __forceinline__ float load_as_float<bf16_t>(const void* src, size_t i)
+{
+    return bf16_bits_to_float(reinterpret_cast<const uint16_t*>(src)[i]);
+}
+template <>
+__device__ __forceinline__ float load_as_float<f16_t>(const void* src, size_t i)
+{
+    return f16_bits_to_float(reinterpret_cast<const uint16_t*>(src)[i]);
+}
+
+__device__ __forceinline__ float block_max_256(float v, float* sm)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0)
+        sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    __syncthreads();
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void per_token_quant_kernel(
+    int8_t* dst, const void* src, int64_t cols, float* scales, float floor_val)
+{
+    __shared__ float sm[4];
+    const size_t base = (size_t) blockIdx.x * cols;
+    float mx = floor_val; // T localMax = 1e-6f (quantization.cu:99)
+    for (int64_t i = threadIdx.x; i < cols; i += 256)
+        mx = fmaxf(mx, fabsf(load_as_float<T>(src, base + i)));
+    mx = block_max_256(mx, sm);
+    if (threadIdx.x == 0)
+        scales[blockIdx.x] = mx / 127.f;
+    const float s = 127.f / mx;
+    for (int64_t i = threadIdx.x; i < cols; i += 256)
+    {
+        float v = rintf(load_as_float<T>(src, base + i) * s); // cvt.rni.sat.s8.f32
+        v = fminf(fmaxf(v, -128.f), 127.f);
+        dst[base + i] = (int8_t) (int) v;
+    }
+}
+
+// ---- e4m3 quantisation (thop/fp8Op.cpp, common/cudaFp8Utils.cu:215-341):
+// scale = max(amax / 448, 1 / (448 * 512)); q = e4m3(x / scale).  mode 0: per row, 2: per tensor
+// (two launches: amax then quantise), mode 1 (per column) uses the column kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_row_quant_kernel(uint8_t* dst, float* scales, const void* src, int64_t cols)
+{
+    __shared__ float sm[4];
+    const size_t base = (size_t) blockIdx.x * cols;
+    float mx = 0.f;
+    for (int64_t i = threadIdx.x; i < cols; i += 256)
+        mx = fmaxf(mx, fabsf(load_as_float<T>(src, base + i)));
+    mx = block_max_256(mx, sm);
+    const float sc = fmaxf(mx / 448.f, 1.f / (448.f * 512.f));
+    if (threadIdx.x == 0)
+        scales[blockIdx.x] = sc;
+    for (int64_t i = threadIdx.x; i < cols; i += 256)
+    {
+        float v = load_as_float<T>(src, base + i) / sc;
+        v = fminf(fmaxf(v, -448.f), 448.f);
+        dst[base + i] = (uint8_t) (__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xff);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_col_quant_kernel(
+    uint8_t* dst, float* scales, const void* src, int64_t rows, int64_t cols)
+{
+    const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols)
+        return;
+    float mx = 0.f;
+    for (int64_t r = 0; r < rows; ++r)
+        mx = fmaxf(mx, fabsf(load_as_float<T>(src, (size_t) r * cols + c)));
+    const float sc = fmaxf(mx / 448.f, 1.f / (448.f * 512.f));
+    scales[c] = sc;
+    for (int64_t r = 0; r < rows; ++r)
+    {
+        float v = load_as_float<T>(src, (size_t) r * cols + c) / sc;
+        v = fminf(fmaxf(v, -448.f), 448.f);
+        dst[(size_t) r * cols + c] = (uint8_t) (__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xff);
+    }
+}
+
+// per-tensor: pass 1 writes max|x| into scales[0] with an integer atomic max on the float bits
+// (valid ordering for non-negative floats); pass 2 quantises.  scales[0] must be zeroed first.
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(float* amax, const void* src, size_t total)
+{
+    __shared__ float sm[4];
+    float mx = 0.f;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t) gridDim.x * 256)
+        mx = fmaxf(mx, fabsf(load_as_float<T>(src, i)));
+    mx = block_max_256(mx, sm);
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(mx));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_tensor_quant_kernel(uint8_t* dst, float* scale, const void* src, size_t total)
+{
+    // every thread derives the scale from the amax pass-1 left in scale[0]; thread 0 of block 0
+    // overwrites it with the scale only after the whole grid has read it -> use a second word.
+    const float sc = fmaxf(scale[1] / 448.f, 1.f / (448.f * 512.f));
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t) gridDim.x * 256)
+    {
+        float v = load_as_float<T>(src, i) / sc;
+        v = fminf(fmaxf(v, -448.f), 448.f);
+        dst[i] = (uint8_t) (__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xff);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        scale[0] = sc;
+}
+
+void check_gemm(int m, int n, int k, const void* A, const void* B, const void* C)
+{
+    MQ_CHECK(A && B && C, "null tensor");
+    MQ_CHECK(m >= 0 && n > 0 && k > 0, "bad m/n/k");
+    MQ_CHECK(k % 16 == 0, "k must be a multiple of 16 (got %d)", k);
+}
+
+} // namespace
+
+void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel, const float* alphaCol,
+    const float* alphaRow, void* C, int out_type, int m, int n, int k, hipStream_t stream)
+{
+    if (m == 0)
+        return;
+    check_gemm(m, n, k, A, B, C);
+    MQ_CHECK(alphaCol && alphaRow, "null scale");
+    // smoothQuantGemmPlugin.cpp:106-130: fp16 / fp32 / int32 outputs (bf16 added here)
+    MQ_CHECK(out_type == MI355Q_HALF || out_type == MI355Q_FLOAT || out_type == MI355Q_INT32 || out_type == MI355Q_BF16,
+        "unsupported SmoothQuant output type %d", out_type);
+    if (m == 0)
+        return;
+    Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, alphaCol, alphaRow,
+        per_token, per_channel, m, n, k, out_type};
+    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm8_kernel<false>), grid, dim3(256), 0, stream, g);
+    MQ_HIP(hipGetLastError());
+}
+
+void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C, int out_type, int m,
+    int n, int k, hipStream_t stream)
+{
+    if (m == 0)
+        return;
+    check_gemm(m, n, k, A, B, C);
+    MQ_CHECK(scaleA && scaleB, "null scale");
+    MQ_CHECK(out_type == MI355Q_HALF || out_type == MI355Q_FLOAT || out_type == MI355Q_BF16,
+        "unsupported fp8 GEMM output type %d", out_type);
+    if (m == 0)
+        return;
+    // per-tensor scales: alpha_row = scaleA[0], alpha_col = scaleB[0]
+    Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, scaleB, scaleA, 0, 0, m,
+        n, k, out_type};
+    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm8_kernel<true>), grid, dim3(256), 0, stream, g);
+    MQ_HIP(hipGetLastError());
+}
+
+void per_token_quantization(
+    int8_t* dst, const void* src, int64_t rows, int64_t cols, float* scales, int src_type, hipStream_t stream)
+{
+    MQ_CHECK(dst && src && scales, "null tensor");
+    if (rows == 0)
+        return;
+    // T(1e-6f) rounded to the source type, as `T localMax = 1e-6f` does
+    switch (src_type)
+    {
+    case MI355Q_FLOAT:
+        hipLaunchKernelGGL((per_token_quant_kernel<float>), dim3((unsigned) rows), dim3(256), 0, stream, dst, src, cols,
+            scales, 1e-6f);
+        break;
+    case MI355Q_HALF:
+        hipLaunchKernelGGL((per_token_quant_kernel<f16_t>), dim3((unsigned) rows), dim3(256), 0, stream, dst, src, cols,
+            scales, 1.013278961181640625e-06f);
+        break;
+    case MI355Q_BF16:
+        hipLaunchKernelGGL((per_token_quant_kernel<bf16_t>), dim3((unsigned) rows), dim3(256), 0, stream, dst, src,
+            cols, scales, 9.98377799987792969e-07f);
+        break;
+    default: MQ_UNSUPPORTED("per-token quantisation of dtype %d", src_type);
+    }
+    MQ_HIP(hipGetLastError());
+}
+
+template <typename T>
+static void quantize_e4m3_t(void* dst, float* scales, const void* src, int64_t rows, int64_t cols, int mode, hipStream_t stream)
+{
+    uint8_t* d = reinterpret_cast<uint8_t*>(dst);
+    if (mode == 0)
+        hipLaunchKernelGGL((fp8_row_quant_kernel<T>), dim3((unsigned) rows), dim3(256), 0, stream, d, scales, src, cols);
+    else if (mode == 1)
+        hipLaunchKernelGGL((fp8_col_quant_kernel<T>), dim3((unsigned) ((cols + 255) / 256)), dim3(256), 0, stream, d,
+            scales, src, rows, cols);
+    else
+    {
+        // scales must have room for 2 floats: [0] = scale (result), [1] = amax scratch
+        MQ_HIP(hipMemsetAsync(scales, 0, 2 * sizeof(float), stream));
+        const size_t total = (size_t) rows * cols;
+        const unsigned blocks = (unsigned) std::min<size_t>(2048, (total + 255) / 256);
+        hipLaunchKernelGGL((fp8_amax_kernel<T>), dim3(blocks), dim3(256), 0, stream, scales + 1, src, total);
+        hipLaunchKernelGGL((fp8_tensor_quant_kernel<T>), dim3(blocks), dim3(256), 0, stream, d, scales, src, total);
+    }
+}
+
+void quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols, int src_type, int mode,
+    hipStream_t stream)
+{
+    MQ_CHECK(dst && src && scales, "null tensor");
+    MQ_CHECK(mode >= 0 && mode <= 2, "mode %d", mode);
+    if (rows == 0 || cols == 0)
+        return;
+    switch (src_type)
+    {
+    case MI355Q_FLOAT: quantize_e4m3_t<float>(dst, scales, src, rows, cols, mode, stream); break;
+    case MI355Q_HALF: quantize_e4m3_t<f16_t>(dst, scales, src, rows, cols, mode, stream); break;
+    case MI355Q_BF16: quantize_e4m3_t<bf16_t>(dst, scales, src, rows, cols, mode, stream); break;
+    default: MQ_UNSUPPORTED("e4m3 quantisation of dtype %d", src_type);
+    }
+    MQ_HIP(hipGetLastError());
+}
+
+} // namespace mi355q

@@ -1,0 +1,40 @@
+// kernels.h -- internal C++ interface between the plugin layer and the HIP kernels.
+#pragma once
+#include "common.h"
+
+namespace mi355q
+{
+
+// preprocess.cpp (host)
+void preprocess_weights(int8_t* dst, const int8_t* src, const size_t shape[3], int weight_type, int layout);
+void unprocess_weights(int8_t* dst, const int8_t* src, const size_t shape[3], int weight_type, int layout);
+void unpack_int4(int8_t* dst, const int8_t* src, size_t numPacked);
+void pack_int4(int8_t* dst, const int8_t* src, size_t numPacked);
+void symmetric_quantize(int8_t* processed, int8_t* unprocessed, float* scales, const float* weight,
+    const size_t shape[3], int weight_type, int layout);
+
+// woq_gemm.hip
+int woq_choose_ksplit(int m, int n, int k, int weight_type);
+size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type);
+void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream);
+void weight_only_dequantize(const mi355q_weight_only_params& p, hipStream_t stream);
+void apply_per_channel_scale(
+    void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream);
+// plugins.cpp: smoothing (if act_scale) + GEMM, carving p.workspace
+void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stream);
+
+// gemm8.hip
+void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel, const float* alphaCol,
+    const float* alphaRow, void* C, int out_type, int m, int n, int k, hipStream_t stream);
+void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C, int out_type, int m,
+    int n, int k, hipStream_t stream);
+void per_token_quantization(
+    int8_t* dst, const void* src, int64_t rows, int64_t cols, float* scales, int src_type, hipStream_t stream);
+void quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols, int src_type, int mode,
+    hipStream_t stream);
+
+// decode_attn.hip
+size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q);
+void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream);
+
+} // namespace mi355q

@@ -1,0 +1,1289 @@
+// plugins.cpp -- host side above the C ABI: the four TensorRT plugin contracts of the hot path,
+// restated without TensorRT types (IPluginV2DynamicExt -> PluginBase), plus the C entry points.
+// Input order, flag compaction, shape arithmetic and error behaviour follow the reference files
+// cited at each class.
+#include "common.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <vector>
+
+namespace mi355q
+{
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg)
+{
+    g_last_error = msg;
+}
+
+std::string fmtstr(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return std::string(buf);
+}
+
+namespace
+{
+
+// plugins/common/plugin.h read/write helpers
+template <typename T>
+void write(char*& p, const T& v)
+{
+    std::memcpy(p, &v, sizeof(T));
+    p += sizeof(T);
+}
+
+template <typename T>
+void read(const char*& p, T& v)
+{
+    std::memcpy(&v, p, sizeof(T));
+    p += sizeof(T);
+}
+
+struct GemmDims // plugins/common/gemmPluginProfiler.h GemmDims
+{
+    int32_t minM = -1, maxM = -1, n = -1, k = -1;
+    bool isInitialized() const
+    {
+        return minM >= 0 && maxM >= 0 && n >= 0 && k >= 0;
+    }
+};
+
+struct FieldReader
+{
+    const mi355q_plugin_field* f;
+    int n;
+    const mi355q_plugin_field* find(const char* name) const
+    {
+        for (int i = 0; i < n; ++i)
+            if (f[i].name && std::strcmp(f[i].name, name) == 0)
+                return &f[i];
+        return nullptr;
+    }
+    bool get_int(const char* name, int64_t& out) const
+    {
+        const mi355q_plugin_field* x = find(name);
+        if (!x || !x->data)
+            return false;
+        switch (x->type)
+        {
+        case MI355Q_FIELD_INT8: out = *static_cast<const int8_t*>(x->data); return true;
+        case MI355Q_FIELD_INT16: out = *static_cast<const int16_t*>(x->data); return true;
+        case MI355Q_FIELD_INT32: out = *static_cast<const int32_t*>(x->data); return true;
+        case MI355Q_FIELD_FLOAT32: out = (int64_t) * static_cast<const float*>(x->data); return true;
+        default: return false;
+        }
+    }
+    int req_int(const char* name) const
+    {
+        int64_t v;
+        MQ_CHECK(get_int(name, v), "plugin field '%s' missing", name);
+        return (int) v;
+    }
+    int opt_int(const char* name, int dflt) const
+    {
+        int64_t v;
+        return get_int(name, v) ? (int) v : dflt;
+    }
+    float opt_float(const char* name, float dflt) const
+    {
+        const mi355q_plugin_field* x = find(name);
+        if (!x || !x->data)
+            return dflt;
+        if (x->type == MI355Q_FIELD_FLOAT32)
+            return *static_cast<const float*>(x->data);
+        if (x->type == MI355Q_FIELD_FLOAT64)
+            return (float) *static_cast<const double*>(x->data);
+        int64_t v;
+        return get_int(name, v) ? (float) v : dflt;
+    }
+};
+
+} // namespace
+
+struct PluginBase
+{
+    virtual ~PluginBase() = default;
+    virtual const char* type() const = 0;
+    virtual int nbOutputs() const
+    {
+        return 1;
+    }
+    virtual PluginBase* clone() const = 0;
+    virtual void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const = 0;
+    virtual bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int nbOut) const = 0;
+    virtual int getOutputDataType(int idx, const int32_t* inTypes, int nbIn) const = 0;
+    virtual void configure(const mi355q_dynamic_tensor_desc*, int, const mi355q_dynamic_tensor_desc*, int) {}
+    virtual size_t workspaceSize(const mi355q_tensor_desc*, int, const mi355q_tensor_desc*, int) const
+    {
+        return 0;
+    }
+    virtual void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc* outDesc, const void* const* inputs,
+        void* const* outputs, void* workspace, hipStream_t stream)
+        = 0;
+    virtual size_t serializationSize() const = 0;
+    virtual void serialize(char* buf) const = 0;
+};
+
+namespace
+{
+
+inline size_t align_up(size_t x, size_t a)
+{
+    return (x + a - 1) / a * a;
+}
+
+int rows_of(const mi355q_dims& d)
+{
+    return (int) dims_prod(d, 0, d.nbDims - 1);
+}
+
+// ===================================================================== WeightOnlyGroupwiseQuantMatmul
+// plugins/weightOnlyGroupwiseQuantMatmulPlugin/weightOnlyGroupwiseQuantMatmulPlugin.{h,cpp}
+constexpr int BIAS = 1, ZERO = 2, PRE_QUANT_SCALE = 4, FP8_ALPHA = 8; // :28-34
+constexpr int FP16_INT4_RATIO = 4;                                    // weightOnlyQuantMatmulPlugin.h:48
+constexpr int FP16_INT8_RATIO = 2;
+
+struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
+{
+    int32_t mType, mQuantAlgo, mGroupSize;
+    GemmDims mDims;
+    int mPreQuantScaleInputIdx, mWeightInputIdx, mScalesInputIdx, mZerosInputIdx, mBiasesInputIdx, mAlphaInputIdx;
+    size_t m_workspaceMaxSize = 0;
+
+    WeightOnlyGroupwiseQuantMatmulPlugin(int type, int quant_algo, int group_size)
+    {
+        init(type, quant_algo, group_size);
+    }
+    void init(int type, int quant_algo, int group_size) // :132-229
+    {
+        mType = type;
+        mQuantAlgo = quant_algo;
+        mGroupSize = group_size;
+        mPreQuantScaleInputIdx = (quant_algo & PRE_QUANT_SCALE) ? 1 : 0;
+        mWeightInputIdx = mPreQuantScaleInputIdx + 1;
+        mScalesInputIdx = mWeightInputIdx + 1;
+        mZerosInputIdx = (quant_algo & ZERO) ? mScalesInputIdx + 1 : mScalesInputIdx;
+        mBiasesInputIdx = (quant_algo & BIAS) ? mZerosInputIdx + 1 : mZerosInputIdx;
+        mAlphaInputIdx = (quant_algo & FP8_ALPHA) ? mBiasesInputIdx + 1 : mBiasesInputIdx;
+        if (quant_algo & FP8_ALPHA) // :148-154: Hopper-only in the reference, not built here either
+            MQ_UNSUPPORTED("W4A(fp)8 kernel is unsupported on this architecture!");
+        if (mType != MI355Q_HALF && mType != MI355Q_BF16)
+            MQ_UNSUPPORTED("Unsupported data type");
+        MQ_CHECK(group_size > 0 && group_size % 64 == 0, "group_size must be a multiple of 64 (64 or 128), got %d",
+            group_size);
+    }
+    const char* type() const override
+    {
+        return "WeightOnlyGroupwiseQuantMatmul";
+    }
+    PluginBase* clone() const override
+    {
+        return new WeightOnlyGroupwiseQuantMatmulPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const override // :243-281
+    {
+        MQ_CHECK(nbIn == mAlphaInputIdx + 1, "nbInputs %d != %d", nbIn, mAlphaInputIdx + 1);
+        MQ_CHECK(idx == 0, "outputIndex");
+        const int nbDimsA = in[0].nbDims;
+        MQ_CHECK(nbDimsA >= 2 && in[mWeightInputIdx].nbDims == 2, "ranks");
+        *out = in[0];
+        out->d[nbDimsA - 1] = in[mWeightInputIdx].d[1] * FP16_INT4_RATIO;
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override // :283-308
+    {
+        MQ_CHECK(pos < mAlphaInputIdx + 2, "pos");
+        return io[pos].type == mType && io[pos].format == 0;
+    }
+    int getOutputDataType(int idx, const int32_t*, int) const override
+    {
+        MQ_CHECK(idx == 0, "index");
+        return mType;
+    }
+    void configure(const mi355q_dynamic_tensor_desc* in, int, const mi355q_dynamic_tensor_desc*, int) override // :310-333
+    {
+        const int minM = rows_of(in[0].min), maxM = rows_of(in[0].max);
+        const int maxK = in[0].max.d[in[0].max.nbDims - 1];
+        const int maxN = in[mWeightInputIdx].max.d[1] * FP16_INT4_RATIO;
+        if (!mDims.isInitialized())
+            mDims = {minM, maxM, maxN / FP16_INT4_RATIO, maxK};
+        m_workspaceMaxSize = mi355q_weight_only_gemm_workspace_size(maxM, maxN, maxK, MI355Q_WEIGHT_INT4);
+    }
+    size_t workspaceSize(const mi355q_tensor_desc*, int, const mi355q_tensor_desc*, int) const override
+    {
+        return m_workspaceMaxSize;
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void* workspace, hipStream_t stream) override // :341-517
+    {
+        const int m = rows_of(inDesc[0].dims);
+        const int n = inDesc[mWeightInputIdx].dims.d[1];
+        const int k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
+        mi355q_weight_only_params p{};
+        p.qweight = inputs[mWeightInputIdx];
+        p.scales = inputs[mScalesInputIdx];
+        p.zeros = (mQuantAlgo & ZERO) ? inputs[mZerosInputIdx] : nullptr;
+        p.bias = (mQuantAlgo & BIAS) ? inputs[mBiasesInputIdx] : nullptr;
+        p.act_scale = (mQuantAlgo & PRE_QUANT_SCALE) ? inputs[mPreQuantScaleInputIdx] : nullptr;
+        p.in = inputs[0];
+        p.out = outputs[0];
+        p.m = m;
+        p.n = n * FP16_INT4_RATIO; // real_n, :429
+        p.k = k;
+        p.group_size = mGroupSize;
+        p.weight_type = MI355Q_WEIGHT_INT4;
+        p.act_type = mType;
+        p.workspace = workspace;
+        p.workspace_bytes = workspace ? mi355q_weight_only_gemm_workspace_size(m, p.n, k, MI355Q_WEIGHT_INT4) : 0;
+        if (m_workspaceMaxSize)
+            p.workspace_bytes = std::max(p.workspace_bytes, workspace ? m_workspaceMaxSize : 0);
+        weight_only_gemm_entry(p, stream);
+    }
+    size_t serializationSize() const override // :552-559 (minus the profiler's tactic table)
+    {
+        return sizeof(int32_t) * 3 + sizeof(GemmDims);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mType);
+        write(buf, mQuantAlgo);
+        write(buf, mGroupSize);
+        write(buf, mDims);
+    }
+};
+
+// ===================================================================== WeightOnlyQuantMatmul
+// plugins/weightOnlyQuantMatmulPlugin/weightOnlyQuantMatmulPlugin.{h,cpp}
+struct WeightOnlyQuantMatmulPlugin : PluginBase
+{
+    int32_t mType, mWeightTypeId;
+    GemmDims mDims;
+    size_t m_workspaceMaxSize = 0;
+    WeightOnlyQuantMatmulPlugin(int type, int weightTypeId)
+        : mType(type)
+        , mWeightTypeId(weightTypeId)
+    {
+        MQ_CHECK(weightTypeId == MI355Q_WEIGHT_INT8 || weightTypeId == MI355Q_WEIGHT_INT4, "weight_type_id %d",
+            weightTypeId);
+        if (mType != MI355Q_HALF && mType != MI355Q_BF16)
+            MQ_UNSUPPORTED("Unsupported data type");
+    }
+    int ratio() const
+    {
+        return mWeightTypeId == MI355Q_WEIGHT_INT4 ? 2 : 1; // INT8_INT4_RATIO, :317-320
+    }
+    const char* type() const override
+    {
+        return "WeightOnlyQuantMatmul";
+    }
+    PluginBase* clone() const override
+    {
+        return new WeightOnlyQuantMatmulPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const override // :168-205
+    {
+        MQ_CHECK(nbIn == 3 && idx == 0, "nbInputs / outputIndex");
+        MQ_CHECK(in[0].nbDims >= 2 && in[1].nbDims == 2, "ranks");
+        *out = in[0];
+        out->d[in[0].nbDims - 1] = in[1].d[1] * ratio();
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override // :207-241
+    {
+        switch (pos)
+        {
+        case 0: return io[0].type == mType && io[0].format == 0;
+        case 1: return io[1].type == MI355Q_INT8 && io[1].format == 0; // int4 weights are reported as kINT8
+        case 2: return io[2].type == mType && io[2].format == 0;
+        case 3: return io[3].type == mType && io[3].format == 0;
+        default: MQ_CHECK(false, "pos %d", pos); return false;
+        }
+    }
+    int getOutputDataType(int idx, const int32_t*, int) const override
+    {
+        MQ_CHECK(idx == 0, "index");
+        return mType;
+    }
+    void configure(const mi355q_dynamic_tensor_desc* in, int, const mi355q_dynamic_tensor_desc*, int) override // :243-266
+    {
+        const int minM = rows_of(in[0].min), maxM = rows_of(in[0].max);
+        const int maxK = in[0].max.d[in[0].max.nbDims - 1];
+        const int maxN = in[1].max.d[1] * ratio();
+        if (!mDims.isInitialized())
+            mDims = {minM, maxM, maxN / ratio(), maxK};
+        m_workspaceMaxSize = mi355q_weight_only_gemm_workspace_size(maxM, maxN, maxK, mWeightTypeId);
+    }
+    size_t workspaceSize(const mi355q_tensor_desc*, int, const mi355q_tensor_desc*, int) const override
+    {
+        return m_workspaceMaxSize;
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void* workspace, hipStream_t stream) override // :273-347
+    {
+        mi355q_weight_only_params p{};
+        p.m = rows_of(inDesc[0].dims);
+        p.n = inDesc[1].dims.d[1] * ratio();
+        p.k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
+        p.in = inputs[0];
+        p.qweight = inputs[1];
+        p.scales = inputs[2];
+        p.out = outputs[0];
+        p.group_size = 0; // PER_COLUMN_SCALE_ONLY
+        p.weight_type = mWeightTypeId;
+        p.act_type = mType;
+        p.workspace = workspace;
+        p.workspace_bytes = workspace ? std::max(m_workspaceMaxSize,
+                                mi355q_weight_only_gemm_workspace_size(p.m, p.n, p.k, mWeightTypeId))
+                                      : 0;
+        weight_only_gemm_entry(p, stream);
+    }
+    size_t serializationSize() const override // :384-399
+    {
+        return sizeof(int32_t) * 2 + sizeof(GemmDims);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mType);
+        write(buf, mWeightTypeId);
+        write(buf, mDims);
+    }
+};
+
+// ===================================================================== SmoothQuantGemm
+// plugins/smoothQuantGemmPlugin/smoothQuantGemmPlugin.{h,cpp}; QuantMode bits common/quantization.h:44-91
+struct SmoothQuantGemmPlugin : PluginBase
+{
+    int32_t mQuantMode; // perChannelScaling = 1<<3, perTokenScaling = 1<<4
+    int32_t mType;
+    GemmDims mDims;
+    SmoothQuantGemmPlugin(int quantMode, int type)
+        : mQuantMode(quantMode)
+        , mType(type)
+    {
+        // init(), :106-130
+        if (mType != MI355Q_HALF && mType != MI355Q_FLOAT && mType != MI355Q_INT32 && mType != MI355Q_BF16)
+            MQ_UNSUPPORTED("Support for the requested SmoothQuant output type is missing");
+    }
+    bool perChannel() const
+    {
+        return mQuantMode & (1 << 3);
+    }
+    bool perToken() const
+    {
+        return mQuantMode & (1 << 4);
+    }
+    const char* type() const override
+    {
+        return "SmoothQuantGemm";
+    }
+    PluginBase* clone() const override
+    {
+        return new SmoothQuantGemmPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const override // :143-166
+    {
+        MQ_CHECK(nbIn == 4 && idx == 0, "nbInputs / outputIndex");
+        MQ_CHECK(in[0].nbDims >= 2 && in[1].nbDims == 2, "ranks");
+        *out = in[0];
+        out->d[in[0].nbDims - 1] = in[1].d[0];
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override // :168-190
+    {
+        switch (pos)
+        {
+        case 0:
+        case 1: return io[pos].type == MI355Q_INT8 && io[pos].format == 0;
+        case 2:
+        case 3: return io[pos].type == MI355Q_FLOAT && io[pos].format == 0;
+        case 4: return io[pos].type == mType && io[pos].format == 0;
+        default: MQ_CHECK(false, "pos %d", pos); return false;
+        }
+    }
+    int getOutputDataType(int idx, const int32_t*, int) const override
+    {
+        MQ_CHECK(idx == 0, "index");
+        return mType;
+    }
+    void configure(const mi355q_dynamic_tensor_desc* in, int, const mi355q_dynamic_tensor_desc*, int) override
+    {
+        if (!mDims.isInitialized())
+            mDims = {rows_of(in[0].min), rows_of(in[0].max), in[1].max.d[0], in[0].max.d[in[0].max.nbDims - 1]};
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override // :220-247
+    {
+        const int m = rows_of(inDesc[0].dims);
+        const int n = inDesc[1].dims.d[0];
+        const int k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
+        int8_gemm(static_cast<const int8_t*>(inputs[0]), static_cast<const int8_t*>(inputs[1]), perToken(),
+            perChannel(), static_cast<const float*>(inputs[3]), static_cast<const float*>(inputs[2]), outputs[0], mType,
+            m, n, k, stream);
+    }
+    size_t serializationSize() const override // :288-296
+    {
+        return sizeof(int32_t) * 2 + sizeof(GemmDims);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mQuantMode);
+        write(buf, mType);
+        write(buf, mDims);
+    }
+};
+
+// ===================================================================== QuantizePerToken
+// plugins/quantizePerTokenPlugin/quantizePerTokenPlugin.cpp: in [.., K] fp16/bf16/fp32 ->
+// out0 int8 [.., K], out1 fp32 [.., 1]
+struct QuantizePerTokenPlugin : PluginBase
+{
+    const char* type() const override
+    {
+        return "QuantizePerToken";
+    }
+    int nbOutputs() const override
+    {
+        return 2;
+    }
+    PluginBase* clone() const override
+    {
+        return new QuantizePerTokenPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const override
+    {
+        MQ_CHECK(nbIn == 1 && idx < 2, "nbInputs / outputIndex");
+        *out = in[0];
+        if (idx == 1)
+            out->d[in[0].nbDims - 1] = 1;
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override
+    {
+        switch (pos)
+        {
+        case 0:
+            return (io[0].type == MI355Q_FLOAT || io[0].type == MI355Q_HALF || io[0].type == MI355Q_BF16)
+                && io[0].format == 0;
+        case 1: return io[1].type == MI355Q_INT8 && io[1].format == 0;
+        case 2: return io[2].type == MI355Q_FLOAT && io[2].format == 0;
+        default: MQ_CHECK(false, "pos %d", pos); return false;
+        }
+    }
+    int getOutputDataType(int idx, const int32_t*, int) const override
+    {
+        MQ_CHECK(idx < 2, "index");
+        return idx == 0 ? MI355Q_INT8 : MI355Q_FLOAT;
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override
+    {
+        const int m = rows_of(inDesc[0].dims);
+        const int k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
+        per_token_quantization(
+            static_cast<int8_t*>(outputs[0]), inputs[0], m, k, static_cast<float*>(outputs[1]), inDesc[0].type, stream);
+    }
+    size_t serializationSize() const override
+    {
+        return 0;
+    }
+    void serialize(char*) const override {}
+};
+
+// ===================================================================== Fp8Gemm (no reference plugin)
+// inputs: 0 A e4m3 [.., K]; 1 B e4m3 [N, K]; 2 scale_a fp32 [1]; 3 scale_b fp32 [1]
+struct Fp8GemmPlugin : PluginBase
+{
+    int32_t mType;
+    explicit Fp8GemmPlugin(int type)
+        : mType(type)
+    {
+        if (mType != MI355Q_HALF && mType != MI355Q_FLOAT && mType != MI355Q_BF16)
+            MQ_UNSUPPORTED("Unsupported fp8 GEMM output type");
+    }
+    const char* type() const override
+    {
+        return "Fp8Gemm";
+    }
+    PluginBase* clone() const override
+    {
+        return new Fp8GemmPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const override
+    {
+        MQ_CHECK(nbIn == 4 && idx == 0, "nbInputs / outputIndex");
+        *out = in[0];
+        out->d[in[0].nbDims - 1] = in[1].d[0];
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override
+    {
+        if (pos < 2)
+            return io[pos].type == MI355Q_FP8 && io[pos].format == 0;
+        if (pos < 4)
+            return io[pos].type == MI355Q_FLOAT && io[pos].format == 0;
+        return io[pos].type == mType && io[pos].format == 0;
+    }
+    int getOutputDataType(int, const int32_t*, int) const override
+    {
+        return mType;
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override
+    {
+        const int m = rows_of(inDesc[0].dims);
+        const int n = inDesc[1].dims.d[0];
+        const int k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
+        fp8_gemm(inputs[0], inputs[1], static_cast<const float*>(inputs[2]), static_cast<const float*>(inputs[3]),
+            outputs[0], mType, m, n, k, stream);
+    }
+    size_t serializationSize() const override
+    {
+        return sizeof(int32_t);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mType);
+    }
+};
+
+// ===================================================================== GPTAttention
+// plugins/gptAttentionPlugin/gptAttentionPlugin.{h,cpp} + gptAttentionCommon/gptAttentionCommon.cpp
+struct GptAttentionFields // constructor arguments, gptAttentionPlugin.h:73-84
+{
+    int32_t layer_idx = 0, num_heads = 0, num_kv_heads = 0, head_size = 0, unidirectional = 1;
+    float q_scaling = 1.f;
+    int32_t position_embedding_type = 0, rotary_embedding_dim = 0;
+    float rotary_embedding_base = 10000.f;
+    int32_t rotary_embedding_scale_type = 0;
+    float rotary_embedding_scale = 1.f;
+    int32_t rotary_embedding_max_positions = 0, tp_size = 1, tp_rank = 0, unfuse_qkv_gemm = 0;
+    int32_t context_fmha_type = 0, multi_block_mode = 0, enable_xqa = 0, kv_cache_quant_mode = 0;
+    int32_t remove_input_padding = 0, mask_type = 1, paged_kv_cache = 0, tokens_per_block = 0;
+    int32_t type = MI355Q_HALF, max_context_length = 0, qkv_bias_enabled = 0, cross_attention = 0;
+    int32_t max_distance = 0, pos_shift_enabled = 0, dense_context_fmha = 0, use_paged_context_fmha = 0;
+    int32_t use_cache = 1, is_medusa_enabled = 0;
+};
+
+struct GPTAttentionPlugin : PluginBase
+{
+    GptAttentionFields f;
+    enum IdxEntry // gptAttentionPlugin.h:150-177
+    {
+        QKV_TENSOR,
+        K_TENSOR,
+        V_TENSOR,
+        SEQUENCE_LENGTH,
+        HOST_PAST_KEY_VALUE_LENGTHS,
+        HOST_MAX_ATTENTION_WINDOW,
+        HOST_SINK_TOKEN_LENGTH,
+        CONTEXT_LENGTHS,
+        CACHE_INDIR,
+        REQUEST_TYPES,
+        KV_CACHE_BLOCK_POINTERS,
+        HOST_KV_CACHE_BLOCK_POINTERS,
+        PAST_KEY_VALUE,
+        KV_CACHE_QUANTIZATION_SCALE,
+        KV_CACHE_DEQUANTIZATION_SCALE,
+        ALIBI_SLOPES,
+        RELATIVE_ATTENTION_BIAS,
+        CROSS_QKV,
+        CROSS_QKV_LENGTH,
+        ENCODER_INPUT_LENGTH,
+        HOST_CONTEXT_LENGTH,
+        QKV_BIAS_TENSOR,
+        MEDUSA_PACKED_MASK,
+        MEDUSA_POSITION_OFFSETS,
+        ENUM_SIZE
+    };
+    int mEntryIdx[ENUM_SIZE];
+
+    explicit GPTAttentionPlugin(const GptAttentionFields& fields)
+        : f(fields)
+    {
+        MQ_CHECK(f.num_heads > 0 && f.head_size > 0, "num_heads / head_size");
+        if (f.num_kv_heads <= 0)
+            f.num_kv_heads = f.num_heads;
+        MQ_CHECK(f.num_heads % f.num_kv_heads == 0, "num_heads %% num_kv_heads");
+        if (f.type != MI355Q_HALF && f.type != MI355Q_BF16)
+            MQ_UNSUPPORTED("GPTAttention: only fp16 / bf16 activations are built (type_id %d)", f.type);
+        initEntryIdx();
+    }
+    bool hasKvQuant() const
+    {
+        return f.kv_cache_quant_mode & ((1 << 6) | (1 << 7)); // int8KvCache | fp8KvCache
+    }
+    bool isEntryUsed(int e) const // gptAttentionPlugin.cpp:67-97
+    {
+        const bool cache = f.use_cache;
+        switch (e)
+        {
+        case QKV_TENSOR: return true;
+        case K_TENSOR:
+        case V_TENSOR: return f.unfuse_qkv_gemm;
+        case SEQUENCE_LENGTH:
+        case HOST_PAST_KEY_VALUE_LENGTHS: return cache;
+        case HOST_MAX_ATTENTION_WINDOW:
+        case HOST_SINK_TOKEN_LENGTH:
+        case CONTEXT_LENGTHS: return true;
+        case CACHE_INDIR: return cache;
+        case REQUEST_TYPES: return true;
+        case KV_CACHE_BLOCK_POINTERS:
+        case HOST_KV_CACHE_BLOCK_POINTERS: return cache && f.paged_kv_cache;
+        case PAST_KEY_VALUE: return cache && !f.paged_kv_cache;
+        case KV_CACHE_QUANTIZATION_SCALE:
+        case KV_CACHE_DEQUANTIZATION_SCALE: return cache && hasKvQuant();
+        case ALIBI_SLOPES: return f.position_embedding_type == 3 || f.position_embedding_type == 4;
+        case RELATIVE_ATTENTION_BIAS: return f.position_embedding_type == 5;
+        case CROSS_QKV:
+        case CROSS_QKV_LENGTH:
+        case ENCODER_INPUT_LENGTH: return f.cross_attention;
+        case HOST_CONTEXT_LENGTH: return f.remove_input_padding;
+        case QKV_BIAS_TENSOR: return f.qkv_bias_enabled;
+        case MEDUSA_PACKED_MASK:
+        case MEDUSA_POSITION_OFFSETS: return f.is_medusa_enabled;
+        default: return false;
+        }
+    }
+    void initEntryIdx() // :99-108
+    {
+        int idx = 0;
+        for (int i = 0; i < ENUM_SIZE; ++i)
+        {
+            mEntryIdx[i] = idx;
+            idx += isEntryUsed(i);
+        }
+    }
+    int getIdx(int e) const
+    {
+        MQ_CHECK(isEntryUsed(e), "getIdx() should not be used with entry %d", e);
+        return mEntryIdx[e];
+    }
+    int nbInputsExpected() const
+    {
+        int n = 0;
+        for (int i = 0; i < ENUM_SIZE; ++i)
+            n += isEntryUsed(i);
+        return n;
+    }
+    int hiddenDimIndex() const
+    {
+        return f.remove_input_padding ? 1 : 2;
+    }
+    int kvType() const
+    {
+        if (f.kv_cache_quant_mode & (1 << 6))
+            return MI355Q_INT8;
+        if (f.kv_cache_quant_mode & (1 << 7))
+            return MI355Q_FP8;
+        return f.type;
+    }
+    const char* type() const override
+    {
+        return "GPTAttention";
+    }
+    int nbOutputs() const override // present_key_value only for the non-paged cache
+    {
+        return (f.paged_kv_cache || !f.use_cache) ? 1 : 2;
+    }
+    PluginBase* clone() const override
+    {
+        return new GPTAttentionPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int, mi355q_dims* out) const override // :152-164
+    {
+        MQ_CHECK(idx == 0 || (!f.paged_kv_cache && f.use_cache && idx == 1), "outputIndex %d", idx);
+        if (idx == 0)
+        {
+            *out = in[getIdx(QKV_TENSOR)];
+            out->d[hiddenDimIndex()] = f.head_size * f.num_heads;
+        }
+        else
+            *out = in[getIdx(PAST_KEY_VALUE)];
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int) const override // :166-230
+    {
+        auto is = [&](int e) { return isEntryUsed(e) && pos == mEntryIdx[e]; };
+        if (is(CONTEXT_LENGTHS) || is(REQUEST_TYPES) || is(HOST_MAX_ATTENTION_WINDOW) || is(HOST_SINK_TOKEN_LENGTH)
+            || is(MEDUSA_PACKED_MASK) || is(MEDUSA_POSITION_OFFSETS) || is(SEQUENCE_LENGTH)
+            || is(HOST_PAST_KEY_VALUE_LENGTHS) || is(CACHE_INDIR) || is(HOST_CONTEXT_LENGTH)
+            || is(ENCODER_INPUT_LENGTH) || is(CROSS_QKV_LENGTH))
+            return io[pos].type == MI355Q_INT32;
+        if (is(KV_CACHE_QUANTIZATION_SCALE) || is(KV_CACHE_DEQUANTIZATION_SCALE))
+            return io[pos].type == MI355Q_FLOAT && io[pos].format == 0;
+        if (is(KV_CACHE_BLOCK_POINTERS) || is(HOST_KV_CACHE_BLOCK_POINTERS))
+            return io[pos].type == MI355Q_INT64 && io[pos].format == 0;
+        if (is(PAST_KEY_VALUE) || (!f.paged_kv_cache && f.use_cache && pos == nbIn + 1))
+            return io[pos].type == kvType() && io[pos].format == 0;
+        return io[pos].type == f.type && io[pos].format == 0;
+    }
+    int getOutputDataType(int idx, const int32_t* inTypes, int) const override // :300-311
+    {
+        MQ_CHECK(idx == 0 || idx == 1, "index");
+        return idx == 0 ? inTypes[0] : inTypes[getIdx(PAST_KEY_VALUE)];
+    }
+    mi355q_decode_attention_params baseParams(int batch, int max_blocks, int max_seq) const
+    {
+        mi355q_decode_attention_params p{};
+        p.batch = batch;
+        p.num_heads = f.num_heads;
+        p.num_kv_heads = f.num_kv_heads;
+        p.head_size = f.head_size;
+        p.max_blocks_per_seq = max_blocks;
+        p.tokens_per_block = f.tokens_per_block;
+        p.max_seq_len = max_seq;
+        p.act_type = f.type;
+        p.kv_type = kvType();
+        p.position_embedding_type = f.position_embedding_type;
+        p.rotary_embedding_dim = f.rotary_embedding_dim;
+        p.rotary_embedding_base = f.rotary_embedding_base;
+        p.rotary_embedding_scale_type = f.rotary_embedding_scale_type;
+        p.rotary_embedding_scale = f.rotary_embedding_scale;
+        p.rotary_embedding_max_positions = f.rotary_embedding_max_positions;
+        p.q_scaling = f.q_scaling;
+        p.multi_block_mode = 0;
+        return p;
+    }
+    size_t workspaceSize(const mi355q_tensor_desc* in, int, const mi355q_tensor_desc*, int) const override
+    {
+        // generation workspace only: multi-block partials (gptAttentionCommon.cpp:1231-1274)
+        if (!f.use_cache || !f.paged_kv_cache)
+            return 0;
+        const int batch = in[getIdx(CONTEXT_LENGTHS)].dims.d[0];
+        const auto& bp = in[getIdx(KV_CACHE_BLOCK_POINTERS)].dims;
+        const int max_blocks = bp.d[bp.nbDims - 1];
+        mi355q_decode_attention_params p = baseParams(batch, max_blocks, max_blocks * f.tokens_per_block);
+        return mi355q_decode_attention_workspace_size(&p);
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc* outDesc, const void* const* inputs,
+        void* const* outputs, void* workspace, hipStream_t stream) override // :336-393, :396-656
+    {
+        const int nbSeq = inDesc[getIdx(CONTEXT_LENGTHS)].dims.d[0];
+        const int32_t* reqTypes = static_cast<const int32_t*>(inputs[getIdx(REQUEST_TYPES)]);
+        int nbContext = 0;
+        for (int i = 0; i < nbSeq && reqTypes[i] == 0; ++i)
+            ++nbContext;
+        for (int i = nbContext; i < nbSeq; ++i)
+            MQ_CHECK(reqTypes[i] == 1, "host_request_types: context requests must come first (seq %d)", i);
+        if (nbContext > 0)
+            MQ_UNSUPPORTED(
+                "GPTAttention: the context (prefill) phase is not built in this library (SURVEY 8f 'next'); "
+                "only generation requests can be enqueued");
+        if (nbSeq == 0)
+            return;
+        MQ_CHECK(f.use_cache, "KV-cache-less is only supported for context");
+        if (!f.paged_kv_cache)
+            MQ_UNSUPPORTED("GPTAttention: only the paged KV cache (KVBlockArray) is built");
+        if (f.cross_attention || f.is_medusa_enabled || f.unfuse_qkv_gemm || f.pos_shift_enabled)
+            MQ_UNSUPPORTED("GPTAttention: cross attention / medusa / unfused qkv / pos_shift are not built");
+        const auto& indir = inDesc[getIdx(CACHE_INDIR)].dims;
+        const int beamWidth = indir.d[1];
+        if (beamWidth != 1)
+            MQ_UNSUPPORTED("GPTAttention: beam_width %d (only 1 is built)", beamWidth);
+        const int max_attention_window = indir.d[2];
+        const int cyclic_window = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
+        const int sink = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
+        const int32_t* past = static_cast<const int32_t*>(inputs[getIdx(HOST_PAST_KEY_VALUE_LENGTHS)]);
+        const int max_past = *std::max_element(past, past + nbSeq);
+        if (sink != 0 || cyclic_window < max_past + 1)
+            MQ_UNSUPPORTED("GPTAttention: cyclic / sink-token cache addressing is not built (window %d, sink %d)",
+                cyclic_window, sink);
+        (void) max_attention_window;
+
+        const auto& qkvDims = inDesc[getIdx(QKV_TENSOR)].dims;
+        const int hidden = qkvDims.d[hiddenDimIndex()];
+        MQ_CHECK(hidden == (f.num_heads + 2 * f.num_kv_heads) * f.head_size, "qkv hidden size %d", hidden);
+        const int tokens = f.remove_input_padding ? qkvDims.d[0] : qkvDims.d[0] * qkvDims.d[1];
+        MQ_CHECK(tokens == nbSeq, "Only Medusa mode supports input length > 1 in the generation phase");
+
+        const auto& bpDims = inDesc[getIdx(KV_CACHE_BLOCK_POINTERS)].dims; // [layers, B, 2, max_blocks]
+        const int max_blocks = bpDims.d[bpDims.nbDims - 1];
+        const int64_t seqStride = dims_prod(bpDims, 2, bpDims.nbDims);
+        const int64_t layerOffset = (int64_t) f.layer_idx * bpDims.d[1] * seqStride; // :506-519
+
+        mi355q_decode_attention_params p = baseParams(nbSeq, max_blocks, max_past + 1);
+        p.qkv = inputs[getIdx(QKV_TENSOR)];
+        p.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
+        p.out = outputs[0];
+        p.sequence_lengths = static_cast<const int32_t*>(inputs[getIdx(SEQUENCE_LENGTH)]);
+        p.block_pointers = static_cast<const int64_t*>(inputs[getIdx(KV_CACHE_BLOCK_POINTERS)]) + layerOffset;
+        if (hasKvQuant())
+        {
+            p.kv_scale_orig_quant = static_cast<const float*>(inputs[getIdx(KV_CACHE_QUANTIZATION_SCALE)]);
+            p.kv_scale_quant_orig = static_cast<const float*>(inputs[getIdx(KV_CACHE_DEQUANTIZATION_SCALE)]);
+        }
+        p.workspace = workspace;
+        p.workspace_bytes = workspace ? mi355q_decode_attention_workspace_size(&p) : 0;
+        (void) outDesc;
+        masked_multihead_attention(p, stream);
+    }
+    size_t serializationSize() const override
+    {
+        return sizeof(GptAttentionFields);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, f);
+    }
+};
+
+GptAttentionFields parse_attention_fields(const FieldReader& r) // gptAttentionPlugin.cpp:700-790
+{
+    GptAttentionFields f;
+    f.layer_idx = r.opt_int("layer_idx", 0);
+    f.num_heads = r.req_int("num_heads");
+    f.num_kv_heads = r.opt_int("num_kv_heads", 0);
+    f.head_size = r.req_int("head_size");
+    f.unidirectional = r.opt_int("unidirectional", 1);
+    f.q_scaling = r.opt_float("q_scaling", 1.f);
+    f.position_embedding_type = r.opt_int("position_embedding_type", 0);
+    f.rotary_embedding_dim = r.opt_int("rotary_embedding_dim", 0);
+    f.rotary_embedding_base = r.opt_float("rotary_embedding_base", 10000.f);
+    f.rotary_embedding_scale_type = r.opt_int("rotary_embedding_scale_type", 0);
+    f.rotary_embedding_scale = r.opt_float("rotary_embedding_scale", 1.f);
+    f.rotary_embedding_max_positions = r.opt_int("rotary_embedding_max_positions", 0);
+    f.tp_size = r.opt_int("tp_size", 1);
+    f.tp_rank = r.opt_int("tp_rank", 0);
+    f.unfuse_qkv_gemm = r.opt_int("unfuse_qkv_gemm", 0);
+    f.context_fmha_type = r.opt_int("context_fmha_type", 0);
+    f.multi_block_mode = r.opt_int("multi_block_mode", 0);
+    f.enable_xqa = r.opt_int("enable_xqa", 0);
+    f.kv_cache_quant_mode = r.opt_int("kv_cache_quant_mode", 0);
+    f.remove_input_padding = r.opt_int("remove_input_padding", 0);
+    f.mask_type = r.opt_int("mask_type", 1);
+    f.paged_kv_cache = r.opt_int("paged_kv_cache", 0);
+    f.tokens_per_block = r.opt_int("tokens_per_block", 0);
+    f.type = r.req_int("type_id");
+    f.max_context_length = r.opt_int("max_context_length", 0);
+    f.qkv_bias_enabled = r.opt_int("qkv_bias_enabled", 0);
+    f.cross_attention = r.opt_int("do_cross_attention", 0);
+    f.max_distance = r.opt_int("max_distance", 0);
+    f.pos_shift_enabled = r.opt_int("pos_shift_enabled", 0);
+    f.dense_context_fmha = r.opt_int("dense_context_fmha", 0);
+    f.use_paged_context_fmha = r.opt_int("use_paged_context_fmha", 0);
+    f.use_cache = r.opt_int("use_cache", 1);
+    f.is_medusa_enabled = r.opt_int("is_medusa_enabled", 0);
+    return f;
+}
+
+const char* const kPluginNames[] = {"WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
+    "QuantizePerToken", "GPTAttention", "Fp8Gemm", nullptr};
+
+PluginBase* create_plugin(const char* name, const FieldReader& r)
+{
+    const std::string n(name);
+    if (n == "WeightOnlyGroupwiseQuantMatmul")
+        return new WeightOnlyGroupwiseQuantMatmulPlugin(r.req_int("type_id"), r.req_int("quant_algo"), r.req_int("group_size"));
+    if (n == "WeightOnlyQuantMatmul")
+        return new WeightOnlyQuantMatmulPlugin(r.req_int("type_id"), r.req_int("weight_type_id"));
+    if (n == "SmoothQuantGemm")
+    {
+        // createPlugin, smoothQuantGemmPlugin.cpp:335-370: QuantMode from the two booleans
+        const int mode = (r.req_int("has_per_channel_scaling") ? (1 << 3) : 0)
+            | (r.req_int("has_per_token_scaling") ? (1 << 4) : 0);
+        return new SmoothQuantGemmPlugin(mode, r.req_int("type_id"));
+    }
+    if (n == "QuantizePerToken")
+        return new QuantizePerTokenPlugin();
+    if (n == "GPTAttention")
+        return new GPTAttentionPlugin(parse_attention_fields(r));
+    if (n == "Fp8Gemm")
+        return new Fp8GemmPlugin(r.req_int("type_id"));
+    MQ_CHECK(false, "unknown plugin '%s'", name);
+    return nullptr;
+}
+
+PluginBase* deserialize_plugin(const char* name, const void* data, size_t length)
+{
+    const std::string n(name);
+    const char* d = static_cast<const char*>(data);
+    const char* a = d;
+    PluginBase* out = nullptr;
+    auto need = [&](size_t bytes)
+    {
+        MQ_CHECK(length == bytes,
+            "Expected length (%d) != real length (%d). This is often caused by using different TensorRT-LLM version to "
+            "build engine and run engine.",
+            (int) length, (int) bytes);
+    };
+    if (n == "WeightOnlyGroupwiseQuantMatmul")
+    {
+        need(sizeof(int32_t) * 3 + sizeof(GemmDims));
+        int32_t t, q, g;
+        read(d, t);
+        read(d, q);
+        read(d, g);
+        auto* p = new WeightOnlyGroupwiseQuantMatmulPlugin(t, q, g);
+        read(d, p->mDims);
+        out = p;
+    }
+    else if (n == "WeightOnlyQuantMatmul")
+    {
+        need(sizeof(int32_t) * 2 + sizeof(GemmDims));
+        int32_t t, w;
+        read(d, t);
+        read(d, w);
+        auto* p = new WeightOnlyQuantMatmulPlugin(t, w);
+        read(d, p->mDims);
+        out = p;
+    }
+    else if (n == "SmoothQuantGemm")
+    {
+        need(sizeof(int32_t) * 2 + sizeof(GemmDims));
+        int32_t q, t;
+        read(d, q);
+        read(d, t);
+        auto* p = new SmoothQuantGemmPlugin(q, t);
+        read(d, p->mDims);
+        out = p;
+    }
+    else if (n == "QuantizePerToken")
+    {
+        need(0);
+        out = new QuantizePerTokenPlugin();
+    }
+    else if (n == "GPTAttention")
+    {
+        need(sizeof(GptAttentionFields));
+        GptAttentionFields f;
+        read(d, f);
+        out = new GPTAttentionPlugin(f);
+    }
+    else if (n == "Fp8Gemm")
+    {
+        need(sizeof(int32_t));
+        int32_t t;
+        read(d, t);
+        out = new Fp8GemmPlugin(t);
+    }
+    else
+        MQ_CHECK(false, "unknown plugin '%s'", name);
+    (void) a;
+    return out;
+}
+
+} // namespace
+
+// shared by the plugins and the C entry point: pre-quant smoothing into the workspace, then GEMM
+void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stream)
+{
+    if (p.m == 0)
+        return;
+    mi355q_weight_only_params q = p;
+    char* ws = static_cast<char*>(p.workspace);
+    size_t ws_bytes = p.workspace_bytes;
+    if (p.act_scale && p.m > 0)
+    {
+        // weightOnlyGroupwiseQuantMatmulPlugin.cpp:382-418: smoothed activations go to the workspace
+        const size_t act_bytes = align_up((size_t) p.m * p.k * 2, 256);
+        MQ_CHECK(ws && ws_bytes >= act_bytes, "workspace too small for the smoothed activations (%zu < %zu)", ws_bytes,
+            act_bytes);
+        apply_per_channel_scale(ws, p.in, p.act_scale, p.m, p.k, p.act_type, stream);
+        q.in = ws;
+        q.act_scale = nullptr;
+        ws += act_bytes;
+        ws_bytes -= act_bytes;
+    }
+    weight_only_gemm(q, ws, ws ? ws_bytes : 0, stream);
+}
+
+} // namespace mi355q
+
+// ============================================================================== C entry points
+using namespace mi355q;
+
+struct mi355q_plugin
+{
+    std::unique_ptr<PluginBase> impl;
+};
+
+extern "C"
+{
+
+    const char* mi355q_last_error(void)
+    {
+        return g_last_error.c_str();
+    }
+
+    const char* mi355q_version(void)
+    {
+        return "mi355q 0.1 (gfx950)";
+    }
+
+    mi355q_status mi355q_plugin_create(
+        const char* name, const mi355q_plugin_field* fields, int32_t nbFields, mi355q_plugin** out)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(name && out, "null argument");
+                FieldReader r{fields, fields ? nbFields : 0};
+                std::unique_ptr<PluginBase> p(create_plugin(name, r));
+                *out = new mi355q_plugin{std::move(p)};
+            });
+    }
+
+    mi355q_status mi355q_plugin_deserialize(const char* name, const void* data, size_t length, mi355q_plugin** out)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(name && out && (data || length == 0), "null argument");
+                std::unique_ptr<PluginBase> p(deserialize_plugin(name, data, length));
+                *out = new mi355q_plugin{std::move(p)};
+            });
+    }
+
+    void mi355q_plugin_destroy(mi355q_plugin* p)
+    {
+        delete p;
+    }
+
+    mi355q_status mi355q_plugin_clone(const mi355q_plugin* p, mi355q_plugin** out)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(p && out, "null argument");
+                *out = new mi355q_plugin{std::unique_ptr<PluginBase>(p->impl->clone())};
+            });
+    }
+
+    const char* mi355q_plugin_type(const mi355q_plugin* p)
+    {
+        return p ? p->impl->type() : "";
+    }
+
+    int32_t mi355q_plugin_nb_outputs(const mi355q_plugin* p)
+    {
+        return p ? p->impl->nbOutputs() : 0;
+    }
+
+    mi355q_status mi355q_plugin_get_output_dimensions(
+        const mi355q_plugin* p, int32_t outputIndex, const mi355q_dims* inputs, int32_t nbInputs, mi355q_dims* out)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(p && inputs && out, "null argument");
+                p->impl->getOutputDimensions(outputIndex, inputs, nbInputs, out);
+            });
+    }
+
+    int32_t mi355q_plugin_supports_format_combination(
+        const mi355q_plugin* p, int32_t pos, const mi355q_tensor_desc* inOut, int32_t nbInputs, int32_t nbOutputs)
+    {
+        int32_t res = 0;
+        mi355q_status s = guarded(
+            [&]
+            {
+                MQ_CHECK(p && inOut && pos >= 0 && pos < nbInputs + nbOutputs, "bad argument");
+                res = p->impl->supportsFormatCombination(pos, inOut, nbInputs, nbOutputs) ? 1 : 0;
+            });
+        return s == MI355Q_OK ? res : (int32_t) s;
+    }
+
+    int32_t mi355q_plugin_get_output_data_type(
+        const mi355q_plugin* p, int32_t index, const int32_t* inputTypes, int32_t nbInputs)
+    {
+        int32_t res = 0;
+        mi355q_status s = guarded(
+            [&]
+            {
+                MQ_CHECK(p, "null argument");
+                res = p->impl->getOutputDataType(index, inputTypes, nbInputs);
+            });
+        return s == MI355Q_OK ? res : (int32_t) s;
+    }
+
+    mi355q_status mi355q_plugin_configure(mi355q_plugin* p, const mi355q_dynamic_tensor_desc* in, int32_t nbInputs,
+        const mi355q_dynamic_tensor_desc* out, int32_t nbOutputs)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(p && in, "null argument");
+                p->impl->configure(in, nbInputs, out, nbOutputs);
+            });
+    }
+
+    size_t mi355q_plugin_get_workspace_size(const mi355q_plugin* p, const mi355q_tensor_desc* inputs, int32_t nbInputs,
+        const mi355q_tensor_desc* outputs, int32_t nbOutputs)
+    {
+        size_t res = 0;
+        guarded(
+            [&]
+            {
+                MQ_CHECK(p, "null argument");
+                res = p->impl->workspaceSize(inputs, nbInputs, outputs, nbOutputs);
+            });
+        return res;
+    }
+
+    int32_t mi355q_plugin_enqueue(mi355q_plugin* p, const mi355q_tensor_desc* inputDesc,
+        const mi355q_tensor_desc* outputDesc, const void* const* inputs, void* const* outputs, void* workspace,
+        void* stream)
+    {
+        return (int32_t) guarded(
+            [&]
+            {
+                MQ_CHECK(p && inputDesc && inputs && outputs, "null argument");
+                p->impl->enqueue(inputDesc, outputDesc, inputs, outputs, workspace, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    size_t mi355q_plugin_get_serialization_size(const mi355q_plugin* p)
+    {
+        return p ? p->impl->serializationSize() : 0;
+    }
+
+    mi355q_status mi355q_plugin_serialize(const mi355q_plugin* p, void* buffer)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(p && (buffer || p->impl->serializationSize() == 0), "null argument");
+                p->impl->serialize(static_cast<char*>(buffer));
+            });
+    }
+
+    const char* const* mi355q_get_plugin_names(int32_t* nbPlugins)
+    {
+        if (nbPlugins)
+            *nbPlugins = 6;
+        return kPluginNames;
+    }
+
+    mi355q_status mi355q_preprocess_weights_for_mixed_gemm(
+        int8_t* dst, const int8_t* src, const size_t shape[3], int32_t weight_type, int32_t layout)
+    {
+        return guarded([&] { preprocess_weights(dst, src, shape, weight_type, layout); });
+    }
+
+    mi355q_status mi355q_unprocess_weights_for_mixed_gemm(
+        int8_t* dst, const int8_t* src, const size_t shape[3], int32_t weight_type, int32_t layout)
+    {
+        return guarded([&] { unprocess_weights(dst, src, shape, weight_type, layout); });
+    }
+
+    mi355q_status mi355q_unpack_int4_packed_tensor_to_int8(int8_t* dst, const int8_t* src, size_t numPacked)
+    {
+        return guarded([&] { unpack_int4(dst, src, numPacked); });
+    }
+
+    mi355q_status mi355q_pack_int8_tensor_to_packed_int4(int8_t* dst, const int8_t* src, size_t numPacked)
+    {
+        return guarded([&] { pack_int4(dst, src, numPacked); });
+    }
+
+    mi355q_status mi355q_symmetric_quantize(int8_t* processed, int8_t* unprocessed, float* scales, const float* weight,
+        const size_t shape[3], int32_t weight_type, int32_t layout)
+    {
+        return guarded([&] { symmetric_quantize(processed, unprocessed, scales, weight, shape, weight_type, layout); });
+    }
+
+    size_t mi355q_weight_only_gemm_workspace_size(int32_t max_m, int32_t n, int32_t k, int32_t weight_type)
+    {
+        if (max_m <= 0 || n <= 0 || k <= 0)
+            return 0;
+        return align_up((size_t) max_m * k * 2, 256) + woq_gemm_workspace_size(max_m, n, k, weight_type);
+    }
+
+    mi355q_status mi355q_weight_only_gemm(const mi355q_weight_only_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                weight_only_gemm_entry(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_weight_only_dequantize(const mi355q_weight_only_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                weight_only_dequantize(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_apply_per_channel_scale(
+        void* out, const void* act, const void* scale, int32_t rows, int32_t cols, int32_t act_type, void* stream)
+    {
+        return guarded(
+            [&] { apply_per_channel_scale(out, act, scale, rows, cols, act_type, static_cast<hipStream_t>(stream)); });
+    }
+
+    mi355q_status mi355q_int8_gemm(const int8_t* A, const int8_t* B, int32_t per_token, int32_t per_channel,
+        const float* alphaCol, const float* alphaRow, void* C, int32_t out_type, int32_t m, int32_t n, int32_t k,
+        void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                int8_gemm(A, B, per_token, per_channel, alphaCol, alphaRow, C, out_type, m, n, k,
+                    static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_per_token_quantization(int8_t* dst, const void* src, int64_t numRows, int64_t numCols,
+        float* scalePtr, int32_t src_type, void* stream)
+    {
+        return guarded(
+            [&]
+            { per_token_quantization(dst, src, numRows, numCols, scalePtr, src_type, static_cast<hipStream_t>(stream)); });
+    }
+
+    mi355q_status mi355q_fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C,
+        int32_t out_type, int32_t m, int32_t n, int32_t k, void* stream)
+    {
+        return guarded([&] { fp8_gemm(A, B, scaleA, scaleB, C, out_type, m, n, k, static_cast<hipStream_t>(stream)); });
+    }
+
+    mi355q_status mi355q_quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols,
+        int32_t src_type, int32_t mode, void* stream)
+    {
+        return guarded(
+            [&] { quantize_e4m3(dst, scales, src, rows, cols, src_type, mode, static_cast<hipStream_t>(stream)); });
+    }
+
+    size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params)
+    {
+        size_t res = 0;
+        guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                res = decode_attention_workspace_size(*params);
+            });
+        return res;
+    }
+
+    mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                masked_multihead_attention(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    // AllreducePlugin::selectImplementation, plugins/ncclPlugin/allreducePlugin.cpp:111-139
+    int32_t mi355q_allreduce_select_implementation(size_t messageBytes, int32_t worldSize, size_t maxWorkspaceBytes)
+    {
+        if (messageBytes > maxWorkspaceBytes)
+            return MI355Q_AR_RING;
+        if (worldSize <= 2)
+            return MI355Q_AR_ONESHOT;
+        if (worldSize <= 4)
+            return messageBytes < 1 * 1000 * 1000 ? MI355Q_AR_ONESHOT : MI355Q_AR_TWOSHOT;
+        return messageBytes < 500 * 1000 ? MI355Q_AR_ONESHOT : MI355Q_AR_TWOSHOT;
+    }
+}

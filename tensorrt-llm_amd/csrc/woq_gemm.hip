@@ -1,0 +1,398 @@
+// woq_gemm.hip -- weight-only quantized GEMV / GEMM: fp16|bf16 activations x int4|int8 weights
+// (group-wise AWQ/GPTQ scale(+zero) or per-channel scale).  Replaces
+//   kernels/weightOnlyBatchedGemv/{kernel.h,kernelLauncher.cu}  (m < 5, CUDA cores) and
+//   kernels/cutlass_kernels/fpA_intB_gemm/*                      (m >= 5, dequant-in-mainloop)
+// of the reference with one gfx950 design:
+//   * weights live in the GFX950 layout (preprocess.cpp): 1 KiB tiles, one 16-byte load per lane
+//     is already the B fragment of v_mfma_f32_16x16x32 for 32 columns -- no LDS, no shuffles;
+//   * dequantisation in registers with the reference's single-rounding semantic
+//     w = round16(fma(q, scale, zero)) (kernel.h:364-365, mma_tensorop_dequantizer.h:244-252):
+//     v_cvt_f32_i32 (SDWA sign-extending byte select) + v_fma_f32 + v_cvt_pk_{bf16,f16}_f32;
+//     the same device function backs mi355q_weight_only_dequantize, i.e. the bit-exact gate checks
+//     exactly the values the MFMA consumes;
+//   * small m (decode): one workgroup = one 32-column n-block, 8 waves split K, fp32 MFMA
+//     accumulators reduced through LDS -- HBM-bound streaming of the weight tiles;
+//   * optional split-K across workgroups (fp32 slabs in the workspace + a tiny reduce kernel) when
+//     N/32 workgroups cannot fill the chip.
+#include "kernels.h"
+
+namespace mi355q
+{
+
+namespace
+{
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int GEMV_WAVES = 8;
+
+struct WoqArgs
+{
+    const uint4* qweight;
+    const uint16_t* scales;
+    const uint16_t* zeros;
+    const uint16_t* act;
+    const uint16_t* bias;
+    uint16_t* out;
+    float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1
+    int m, n, k;
+    int group; // group size in k; == k for per-channel
+    int ktiles; // k / KTILE
+    int ksplit;
+};
+
+template <typename T>
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4_t c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+        __builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b, f32x4_t c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(
+        __builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sbyte(uint32_t w, int i)
+{
+    return (float) (int8_t) (w >> (8 * i)); // v_cvt_f32_i32_sdwa sext(BYTE_i)
+}
+
+// 8 signed int4 (one dword, nibble j = element j) -> 8 dequantised 16-bit values (4 packed dwords).
+// lo/hi bytes carry 16*q exactly, so the fma uses scale/16 (a power-of-two rescale: exact).
+template <typename T>
+__device__ __forceinline__ uint4 dequant8_int4(uint32_t w, float s16, float z)
+{
+    const uint32_t lo = (w << 4) & 0xf0f0f0f0u; // byte i = 16 * q[2i]
+    const uint32_t hi = w & 0xf0f0f0f0u;        // byte i = 16 * q[2i+1]
+    uint4 r;
+    r.x = pack2<T>(fmaf(sbyte(lo, 0), s16, z), fmaf(sbyte(hi, 0), s16, z));
+    r.y = pack2<T>(fmaf(sbyte(lo, 1), s16, z), fmaf(sbyte(hi, 1), s16, z));
+    r.z = pack2<T>(fmaf(sbyte(lo, 2), s16, z), fmaf(sbyte(hi, 2), s16, z));
+    r.w = pack2<T>(fmaf(sbyte(lo, 3), s16, z), fmaf(sbyte(hi, 3), s16, z));
+    return r;
+}
+
+// 8 signed int8 (two dwords) -> 8 dequantised 16-bit values
+template <typename T>
+__device__ __forceinline__ uint4 dequant8_int8(uint32_t w0, uint32_t w1, float s, float z)
+{
+    uint4 r;
+    r.x = pack2<T>(fmaf(sbyte(w0, 0), s, z), fmaf(sbyte(w0, 1), s, z));
+    r.y = pack2<T>(fmaf(sbyte(w0, 2), s, z), fmaf(sbyte(w0, 3), s, z));
+    r.z = pack2<T>(fmaf(sbyte(w1, 0), s, z), fmaf(sbyte(w1, 1), s, z));
+    r.w = pack2<T>(fmaf(sbyte(w1, 2), s, z), fmaf(sbyte(w1, 3), s, z));
+    return r;
+}
+
+// Dequantise one 1 KiB tile's lane fragment.  frag[t][s]: n-half t (16 columns), k-step s (32 rows).
+// int4: KTILE = 64 (2 k-steps); int8: KTILE = 32 (1 k-step, frag[t][0] only).
+template <typename T, int WBITS, bool ZERO>
+__device__ __forceinline__ void dequant_tile(
+    const uint4& w, const WoqArgs& a, int kt, int n0, int lane, uint4 (&frag)[2][2])
+{
+    constexpr int KTILE = WBITS == 4 ? 64 : 32;
+    const int c = lane & 15;
+    const int g = (kt * KTILE) / a.group; // a tile never straddles a group (group % 64 == 0)
+    const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+    {
+        const size_t si = (size_t) g * a.n + n0 + t * 16 + c;
+        const float s = T16<T>::to_float(a.scales[si]);
+        const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
+        if constexpr (WBITS == 4)
+        {
+            frag[t][0] = dequant8_int4<T>(wd[t * 2 + 0], s * 0.0625f, z);
+            frag[t][1] = dequant8_int4<T>(wd[t * 2 + 1], s * 0.0625f, z);
+        }
+        else
+        {
+            frag[t][0] = dequant8_int8<T>(wd[t * 2 + 0], wd[t * 2 + 1], s, z);
+        }
+    }
+}
+
+// grid: x = n-block (32 columns), y = 16-row chunk of m, z = k split.  block = 8 waves.
+template <typename T, int WBITS, bool ZERO>
+__global__ __launch_bounds__(GEMV_WAVES * 64) void woq_gemv_kernel(WoqArgs a)
+{
+    constexpr int KTILE = WBITS == 4 ? 64 : 32;
+    constexpr int KSTEPS = KTILE / 32;
+    __shared__ float red[GEMV_WAVES][2][64][4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = blockIdx.x;
+    const int m0 = blockIdx.y * 16;
+    const int n0 = nb * 32;
+    const int row = m0 + (lane & 15);
+    const int kh = (lane >> 4) * 8;
+
+    const int per = (a.ktiles + a.ksplit - 1) / a.ksplit;
+    const int kt_begin = blockIdx.z * per;
+    const int kt_end = min(a.ktiles, kt_begin + per);
+
+    const uint4* wbase = a.qweight + (size_t) nb * a.ktiles * 64 + lane;
+    const uint16_t* arow = a.act + (size_t) row * a.k + kh;
+    const bool row_ok = row < a.m;
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+    for (int kt = kt_begin + wave; kt < kt_end; kt += GEMV_WAVES)
+    {
+        const uint4 w = wbase[(size_t) kt * 64];
+        uint4 af[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            af[s] = make_uint4(0, 0, 0, 0);
+            if (row_ok)
+                af[s] = *reinterpret_cast<const uint4*>(arow + (size_t) kt * KTILE + s * 32);
+        }
+        uint4 frag[2][2];
+        dequant_tile<T, WBITS, ZERO>(w, a, kt, n0, lane, frag);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            acc0 = mfma16<T>(af[s], frag[0][s], acc0);
+            acc1 = mfma16<T>(af[s], frag[1][s], acc1);
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+        red[wave][0][lane][r] = acc0[r];
+        red[wave][1][lane][r] = acc1[r];
+    }
+    __syncthreads();
+
+    // 16 x 32 outputs, one per thread: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int om = tid >> 5, on = tid & 31;
+    const int t = on >> 4, src_lane = (om >> 2) * 16 + (on & 15), reg = om & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; ++w)
+        v += red[w][t][src_lane][reg];
+    if (m0 + om < a.m)
+    {
+        const size_t oi = (size_t) (m0 + om) * a.n + n0 + on;
+        if (a.ksplit == 1)
+        {
+            if (a.bias)
+                v += T16<T>::to_float(a.bias[n0 + on]);
+            a.out[oi] = T16<T>::from_float(v);
+        }
+        else
+            a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = v;
+    }
+}
+
+template <typename T>
+__global__ void woq_splitk_reduce_kernel(const float* slabs, const uint16_t* bias, uint16_t* out, int m, int n, int ksplit)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t) m * n)
+        return;
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s)
+        v += slabs[(size_t) s * m * n + i];
+    if (bias)
+        v += T16<T>::to_float(bias[i % n]);
+    out[i] = T16<T>::from_float(v);
+}
+
+// Dense [k, n] dequantised weights from the GFX950 layout (test / tooling path; the reference's
+// tests recover them with an identity matmul, test_weight_only_quant_matmul.py:44-53).
+template <typename T, int WBITS, bool ZERO>
+__global__ void woq_dequant_kernel(WoqArgs a)
+{
+    constexpr int KTILE = WBITS == 4 ? 64 : 32;
+    constexpr int KSTEPS = KTILE / 32;
+    const int lane = threadIdx.x & 63;
+    const int kt = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nb = blockIdx.x;
+    if (kt >= a.ktiles)
+        return;
+    const uint4 w = a.qweight[((size_t) nb * a.ktiles + kt) * 64 + lane];
+    uint4 frag[2][2];
+    dequant_tile<T, WBITS, ZERO>(w, a, kt, nb * 32, lane, frag);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&frag[t][s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const int k = kt * KTILE + s * 32 + (lane >> 4) * 8 + j;
+                const int n = nb * 32 + t * 16 + (lane & 15);
+                a.out[(size_t) k * a.n + n] = (uint16_t) (p[j >> 1] >> (16 * (j & 1)));
+            }
+        }
+}
+
+template <typename T>
+__global__ void per_channel_scale_kernel(uint16_t* out, const uint16_t* act, const uint16_t* scale, int rows, int cols)
+{
+    // 8 elements (16 B) per thread
+    const size_t i = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= (size_t) rows * cols)
+        return;
+    const int c = (int) (i % cols);
+    const uint4 av = *reinterpret_cast<const uint4*>(act + i);
+    const uint4 sv = *reinterpret_cast<const uint4*>(scale + c);
+    const uint32_t* ap = reinterpret_cast<const uint32_t*>(&av);
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(&sv);
+    uint4 r;
+    uint32_t* rp = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        rp[j] = pack2<T>(T16<T>::lo(ap[j]) * T16<T>::lo(sp[j]), T16<T>::hi(ap[j]) * T16<T>::hi(sp[j]));
+    *reinterpret_cast<uint4*>(out + i) = r;
+}
+
+WoqArgs make_args(const mi355q_weight_only_params& p)
+{
+    MQ_CHECK(p.act_type == MI355Q_HALF || p.act_type == MI355Q_BF16, "Unsupported data type %d", p.act_type);
+    MQ_CHECK(p.weight_type == MI355Q_WEIGHT_INT4 || p.weight_type == MI355Q_WEIGHT_INT8, "weight_type %d", p.weight_type);
+    MQ_CHECK(p.qweight && p.scales && p.out, "null tensor");
+    MQ_CHECK(p.n > 0 && p.k > 0 && p.m >= 0, "bad m/n/k");
+    MQ_CHECK(p.k % 64 == 0 && p.n % 32 == 0, "k must be a multiple of 64 and n of 32 (k=%d n=%d)", p.k, p.n);
+    const int group = p.group_size > 0 ? p.group_size : p.k;
+    // fpA_intB_gemm_template.h:136-191: fine-grained => group size 64 or 128 (any multiple of 64 is
+    // accepted here, like the SM90 path)
+    MQ_CHECK(group % 64 == 0 && p.k % group == 0, "group_size %d must be a multiple of 64 dividing k=%d", group, p.k);
+    WoqArgs a{};
+    a.qweight = reinterpret_cast<const uint4*>(p.qweight);
+    a.scales = reinterpret_cast<const uint16_t*>(p.scales);
+    a.zeros = reinterpret_cast<const uint16_t*>(p.zeros);
+    a.act = reinterpret_cast<const uint16_t*>(p.in);
+    a.bias = reinterpret_cast<const uint16_t*>(p.bias);
+    a.out = reinterpret_cast<uint16_t*>(p.out);
+    a.m = p.m;
+    a.n = p.n;
+    a.k = p.k;
+    a.group = group;
+    a.ktiles = p.k / (p.weight_type == MI355Q_WEIGHT_INT4 ? 64 : 32);
+    a.ksplit = 1;
+    return a;
+}
+
+template <typename T, int WBITS, bool ZERO>
+void launch_gemv(const WoqArgs& a, hipStream_t stream)
+{
+    dim3 grid(a.n / 32, (a.m + 15) / 16, a.ksplit);
+    hipLaunchKernelGGL((woq_gemv_kernel<T, WBITS, ZERO>), grid, dim3(GEMV_WAVES * 64), 0, stream, a);
+    if (a.ksplit > 1)
+    {
+        const size_t total = (size_t) a.m * a.n;
+        hipLaunchKernelGGL((woq_splitk_reduce_kernel<T>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream,
+            a.slabs, a.bias, a.out, a.m, a.n, a.ksplit);
+    }
+}
+
+template <typename T, int WBITS, bool ZERO>
+void launch_dequant(const WoqArgs& a, hipStream_t stream)
+{
+    dim3 grid(a.n / 32, (a.ktiles + 3) / 4);
+    hipLaunchKernelGGL((woq_dequant_kernel<T, WBITS, ZERO>), grid, dim3(256), 0, stream, a);
+}
+
+#define MQ_DISPATCH_WOQ(FN, p, a, stream)                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const bool bf = (p).act_type == MI355Q_BF16, i4 = (p).weight_type == MI355Q_WEIGHT_INT4;                       \
+        const bool z = (p).zeros != nullptr;                                                                           \
+        if (bf && i4 && z) FN<bf16_t, 4, true>(a, stream);                                                             \
+        else if (bf && i4) FN<bf16_t, 4, false>(a, stream);                                                            \
+        else if (bf && z) FN<bf16_t, 8, true>(a, stream);                                                              \
+        else if (bf) FN<bf16_t, 8, false>(a, stream);                                                                  \
+        else if (i4 && z) FN<f16_t, 4, true>(a, stream);                                                               \
+        else if (i4) FN<f16_t, 4, false>(a, stream);                                                                   \
+        else if (z) FN<f16_t, 8, true>(a, stream);                                                                     \
+        else FN<f16_t, 8, false>(a, stream);                                                                           \
+    } while (0)
+
+} // namespace
+
+// Split-K heuristic: fill >= 256 workgroups when the n-blocks alone cannot.
+int woq_choose_ksplit(int m, int n, int k, int weight_type)
+{
+    const int ktiles = k / (weight_type == MI355Q_WEIGHT_INT4 ? 64 : 32);
+    const int wgs = (n / 32) * ((m + 15) / 16);
+    if (wgs >= 192)
+        return 1;
+    int s = (256 + wgs - 1) / wgs;
+    s = std::min(s, std::max(1, ktiles / (2 * GEMV_WAVES))); // keep >= 2 tiles per wave
+    return std::max(1, std::min(s, 16));
+}
+
+size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
+{
+    // worst case over all m' <= m of ksplit(m') * m' * n fp32 slabs
+    size_t best = 0;
+    for (int mm = 1; mm <= m; mm = mm < 16 ? mm + 1 : mm + 16)
+    {
+        const int s = woq_choose_ksplit(mm, n, k, weight_type);
+        if (s > 1)
+            best = std::max(best, (size_t) s * mm * n * sizeof(float));
+    }
+    return best;
+}
+
+void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    WoqArgs a = make_args(p);
+    MQ_CHECK(p.in, "null activation");
+    if (p.m == 0)
+        return;
+    MQ_CHECK(p.act_scale == nullptr, "pre-quant scale must be applied with mi355q_apply_per_channel_scale first");
+    a.ksplit = woq_choose_ksplit(p.m, p.n, p.k, p.weight_type);
+    if (a.ksplit > 1)
+    {
+        const size_t need = (size_t) a.ksplit * p.m * p.n * sizeof(float);
+        if (workspace && workspace_bytes >= need)
+            a.slabs = reinterpret_cast<float*>(workspace);
+        else
+            a.ksplit = 1; // correct without workspace, just fewer workgroups
+    }
+    MQ_DISPATCH_WOQ(launch_gemv, p, a, stream);
+    MQ_HIP(hipGetLastError());
+}
+
+void weight_only_dequantize(const mi355q_weight_only_params& p, hipStream_t stream)
+{
+    WoqArgs a = make_args(p);
+    MQ_DISPATCH_WOQ(launch_dequant, p, a, stream);
+    MQ_HIP(hipGetLastError());
+}
+
+void apply_per_channel_scale(void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream)
+{
+    MQ_CHECK(out && act && scale, "null tensor");
+    MQ_CHECK(act_type == MI355Q_HALF || act_type == MI355Q_BF16, "Unsupported data type %d", act_type);
+    MQ_CHECK(cols % 8 == 0, "cols must be a multiple of 8 (preQuantScaleKernel.cu:86-89), got %d", cols);
+    if (rows == 0)
+        return;
+    const size_t vecs = (size_t) rows * cols / 8;
+    dim3 grid((unsigned) ((vecs + 255) / 256));
+    if (act_type == MI355Q_BF16)
+        hipLaunchKernelGGL((per_channel_scale_kernel<bf16_t>), grid, dim3(256), 0, stream, (uint16_t*) out,
+            (const uint16_t*) act, (const uint16_t*) scale, rows, cols);
+    else
+        hipLaunchKernelGGL((per_channel_scale_kernel<f16_t>), grid, dim3(256), 0, stream, (uint16_t*) out,
+            (const uint16_t*) act, (const uint16_t*) scale, rows, cols);
+    MQ_HIP(hipGetLastError());
+}
+
+} // namespace mi355q

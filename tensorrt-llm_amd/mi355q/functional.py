@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference's Python callers of the hot path, executing eagerly.
+
+Same names, argument order and meaning as
+  tensorrt_llm/quantization/functional.py:27-188, 332-359   (smooth_quant_gemm,
+      weight_only_quant_matmul, weight_only_groupwise_quant_matmul, quantize_per_token)
+  tensorrt_llm/functional.py:3487-3930                      (gpt_attention, generation phase)
+  torch.ops.trtllm.* of cpp/tensorrt_llm/thop/weightOnlyQuantOp.cpp
+so the parity tests read like the reference's own tests.  Every function forwards to the C ABI
+through a plugin object exactly as the reference forwards to the TensorRT plugin of the same name.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .plugin import Plugin, str_dtype_to_trt, torch_dtype_to_trt, current_stream_ptr
+
+BIAS, ZERO, PRE_QUANT_SCALE, FP8_ALPHA = 1, 2, 4, 8
+
+
+# ----------------------------------------------------------------------------- thop ops (CPU tensors)
+def _quant_type_id(quant_type):
+    if quant_type in (torch.int8, L.WEIGHT_INT8, "int8"):
+        return L.WEIGHT_INT8
+    if quant_type in (getattr(torch, "quint4x2", None), L.WEIGHT_INT4, "int4"):
+        return L.WEIGHT_INT4
+    raise ValueError("Invalid quantization type: must be torch.int8 or torch.quint4x2")
+
+
+def _shape3(t, quant_type_id):
+    assert t.dim() in (2, 3), "Invalid dim. The dim of weight should be 2 or 3"
+    experts = 1 if t.dim() == 2 else t.shape[0]
+    rows = t.shape[-2]
+    cols = t.shape[-1] * (2 if quant_type_id == L.WEIGHT_INT4 else 1)
+    return (C.c_size_t * 3)(experts, rows, cols)
+
+
+def preprocess_weights_for_mixed_gemm(row_major_quantized_weight, quant_type, layout=L.LAYOUT_GFX950):
+    """torch.ops.trtllm.preprocess_weights_for_mixed_gemm (weightOnlyQuantOp.cpp:116-141).  The
+    reference picks the layout from the GPU's SM version; here the default is the gfx950 layout and
+    the reference's SM80 / SM90 layouts can be requested explicitly."""
+    w = row_major_quantized_weight
+    assert w.device.type == "cpu" and w.dtype == torch.int8 and w.is_contiguous(), \
+        "Quantized tensor must be a contiguous int8 CPU tensor"
+    qt = _quant_type_id(quant_type)
+    out = torch.zeros_like(w)
+    L.check(L.lib().mi355q_preprocess_weights_for_mixed_gemm(out.data_ptr(), w.data_ptr(), _shape3(w, qt), qt, layout))
+    return out
+
+
+def unprocess_weights_for_mixed_gemm(processed_weight, quant_type, layout):
+    """Inverse of the above: any layout -> row-major (for ingesting reference-preprocessed weights)."""
+    w = processed_weight
+    assert w.device.type == "cpu" and w.dtype == torch.int8 and w.is_contiguous()
+    qt = _quant_type_id(quant_type)
+    out = torch.zeros_like(w)
+    L.check(L.lib().mi355q_unprocess_weights_for_mixed_gemm(out.data_ptr(), w.data_ptr(), _shape3(w, qt), qt, layout))
+    return out
+
+
+def unpack_int4_packed_tensor_to_int8(weight):
+    """torch.ops.trtllm.unpack_int4_packed_tensor_to_int8 (weightOnlyQuantOp.cpp:274-306)."""
+    assert weight.device.type == "cpu" and weight.dtype == torch.int8 and weight.numel() != 0
+    w = weight.contiguous()
+    out = torch.zeros(list(w.shape[:-1]) + [w.shape[-1] * 2], dtype=torch.int8)
+    L.check(L.lib().mi355q_unpack_int4_packed_tensor_to_int8(out.data_ptr(), w.data_ptr(), w.numel()))
+    return out
+
+
+def pack_int8_tensor_to_packed_int4(weight):
+    """torch.ops.trtllm.pack_int8_tensor_to_packed_int4 (weightOnlyQuantOp.cpp:308-343)."""
+    assert weight.device.type == "cpu" and weight.dtype == torch.int8 and weight.numel() != 0
+    w = weight.contiguous()
+    out = torch.zeros(list(w.shape[:-1]) + [(w.shape[-1] + 1) // 2], dtype=torch.int8)
+    L.check(L.lib().mi355q_pack_int8_tensor_to_packed_int4(out.data_ptr(), w.data_ptr(), out.numel()))
+    return out
+
+
+def _symmetric_quantize_last_axis_of_batched_matrix(weight, quant_type, layout=L.LAYOUT_GFX950):
+    """torch.ops.trtllm._symmetric_quantize_last_axis_of_batched_matrix (weightOnlyQuantOp.cpp:143-241):
+    returns (unprocessed int8, processed int8, scales in weight.dtype)."""
+    assert weight.device.type == "cpu" and weight.numel() != 0
+    assert weight.dtype in (torch.float32, torch.float16, torch.bfloat16), "Weight must be FP16 or BF16"
+    qt = _quant_type_id(quant_type)
+    wf = weight.float().contiguous()
+    experts = 1 if wf.dim() == 2 else wf.shape[0]
+    rows, cols = wf.shape[-2], wf.shape[-1]
+    bpc = cols * (4 if qt == L.WEIGHT_INT4 else 8) // 8
+    qshape = [rows, bpc] if wf.dim() == 2 else [experts, rows, bpc]
+    unprocessed = torch.empty(qshape, dtype=torch.int8)
+    processed = torch.empty(qshape, dtype=torch.int8)
+    scales = torch.empty([cols] if wf.dim() == 2 else [experts, cols], dtype=torch.float32)
+    shape = (C.c_size_t * 3)(experts, rows, cols)
+    L.check(L.lib().mi355q_symmetric_quantize(processed.data_ptr(), unprocessed.data_ptr(), scales.data_ptr(),
+                                              wf.data_ptr(), shape, qt, layout))
+    return unprocessed, processed, scales.to(weight.dtype)
+
+
+def symmetric_quantize_last_axis_of_batched_matrix(weight, quant_type, layout=L.LAYOUT_GFX950):
+    _, processed, scales = _symmetric_quantize_last_axis_of_batched_matrix(weight, quant_type, layout)
+    return processed, scales
+
+
+# ----------------------------------------------------------------------------- quantized GEMMs (device)
+def _empty_like_opt(t, dtype):
+    return t if t is not None and t.numel() else None
+
+
+def weight_only_groupwise_quant_matmul(input, pre_quant_scale, weights, scales, zeros, biases, alpha,
+                                       quant_algo, group_size, dtype="float16"):
+    """quantization/functional.py:107-188.  `weights` is the preprocessed [K, N/4] tensor typed as
+    the activation dtype (4 int4 per 16-bit element), exactly what the reference feeds the plugin."""
+    plg = Plugin("WeightOnlyGroupwiseQuantMatmul", [
+        ("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32),
+        ("quant_algo", quant_algo, L.FIELD_INT32),
+        ("group_size", group_size, L.FIELD_INT32)])
+    plug_inputs = [input]
+    if quant_algo & PRE_QUANT_SCALE:
+        plug_inputs += [pre_quant_scale]
+    plug_inputs += [weights, scales]
+    if quant_algo & ZERO:
+        plug_inputs += [zeros]
+    if quant_algo & BIAS:
+        plug_inputs += [biases]
+    if quant_algo & FP8_ALPHA:
+        plug_inputs += [alpha]
+    return plg(*plug_inputs)
+
+
+def weight_only_quant_matmul(input, weights, scales, weightTypeId, dtype="float16"):
+    """quantization/functional.py:68-104.  weights: int8 [K, N] (int8) or [K, N/2] (packed int4)."""
+    plg = Plugin("WeightOnlyQuantMatmul", [
+        ("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32),
+        ("weight_type_id", weightTypeId, L.FIELD_INT32)])
+    return plg(input, weights, scales)
+
+
+def smooth_quant_gemm(input, weights, scales_a, scales_b, per_token_scaling, per_channel_scaling,
+                      dtype="float16"):
+    """quantization/functional.py:27-65 (the output dtype is the plugin_config dtype there)."""
+    plg = Plugin("SmoothQuantGemm", [
+        ("has_per_channel_scaling", 1 if per_channel_scaling else 0, L.FIELD_INT32),
+        ("has_per_token_scaling", 1 if per_token_scaling else 0, L.FIELD_INT32),
+        ("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32)])
+    return plg(input, weights, scales_a, scales_b)
+
+
+def quantize_per_token(x):
+    """quantization/functional.py:332-359: returns (int8 tensor, fp32 per-token scales [.., 1])."""
+    return Plugin("QuantizePerToken")(x)
+
+
+def fp8_gemm(input, weights, scale_a, scale_b, dtype="float16"):
+    """FP8Linear semantic (quantization/layers.py:777-879): e4m3 [M,K] x e4m3 [N,K]^T, per-tensor scales."""
+    plg = Plugin("Fp8Gemm", [("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32)])
+    return plg(input, weights, scale_a, scale_b)
+
+
+def quantize_e4m3(x, mode):
+    """torch.ops.tensorrt_llm.quantize_e4m3_{activation,weight,per_tensor} (thop/fp8Op.cpp).
+    mode: 'activation' (per row), 'weight' (per column), 'per_tensor'.  Returns (fp8 tensor, scales)."""
+    m = {"activation": 0, "weight": 1, "per_tensor": 2}[mode]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    rows, cols = x2.shape
+    q = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+    nscale = rows if m == 0 else (cols if m == 1 else 2)
+    scales = torch.empty(nscale, dtype=torch.float32, device=x.device)
+    L.check(L.lib().mi355q_quantize_e4m3(q.data_ptr(), scales.data_ptr(), x2.data_ptr(), rows, cols,
+                                         torch_dtype_to_trt(x.dtype), m, current_stream_ptr()))
+    q = q.view(torch.float8_e4m3fn).reshape(x.shape)
+    if m == 0:
+        return q, scales.reshape(list(x.shape[:-1]) + [1])
+    if m == 1:
+        return q, scales.reshape(1, cols)
+    return q, scales[:1].reshape(1, 1)
+
+
+def dequantize_weights(weights, scales, zeros, k, n, group_size, weight_type, dtype):
+    """Dense [k, n] dequantised weights from the GFX950 layout (the bit-exact gate; the reference
+    tests recover them with an identity matmul, test_weight_only_quant_matmul.py:44-53)."""
+    out = torch.empty(k, n, dtype=dtype, device=weights.device)
+    p = L.WeightOnlyParams()
+    p.qweight = weights.data_ptr()
+    p.scales = scales.data_ptr()
+    p.zeros = zeros.data_ptr() if zeros is not None and zeros.numel() else None
+    p.out = out.data_ptr()
+    p.m, p.n, p.k = 0, n, k
+    p.group_size = group_size
+    p.weight_type = weight_type
+    p.act_type = torch_dtype_to_trt(dtype)
+    L.check(L.lib().mi355q_weight_only_dequantize(C.byref(p), current_stream_ptr()))
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+class PositionEmbeddingType:
+    learned_absolute, rope_gptj, rope_gpt_neox, alibi, alibi_with_scale, relative = range(6)
+
+
+class RotaryScalingType:
+    none, linear, dynamic = range(3)
+
+
+def make_gpt_attention_plugin(*, num_heads, num_kv_heads, head_size, dtype, layer_idx=0, q_scaling=1.0,
+                              position_embedding_type=PositionEmbeddingType.learned_absolute,
+                              rotary_embedding_dim=0, rotary_embedding_base=10000.0,
+                              rotary_embedding_scale_type=RotaryScalingType.none, rotary_embedding_scale=1.0,
+                              rotary_embedding_max_positions=1024, kv_cache_quant_mode=0,
+                              remove_input_padding=False, paged_kv_cache=True, tokens_per_block=64,
+                              max_context_length=0, qkv_bias_enabled=False, multi_block_mode=False,
+                              enable_xqa=True, tp_size=1, tp_rank=0):
+    """Field collection of tensorrt_llm/functional.py:3871-3925 / gptAttentionCommon.cpp:1561-1593."""
+    I8, I32, F32 = L.FIELD_INT8, L.FIELD_INT32, L.FIELD_FLOAT32
+    fields = [
+        ("layer_idx", layer_idx, I32), ("num_heads", num_heads, I32), ("num_kv_heads", num_kv_heads, I32),
+        ("head_size", head_size, I32), ("unidirectional", 1, I32), ("q_scaling", q_scaling, F32),
+        ("position_embedding_type", position_embedding_type, I8),
+        ("rotary_embedding_dim", rotary_embedding_dim, I32), ("rotary_embedding_base", rotary_embedding_base, F32),
+        ("rotary_embedding_scale_type", rotary_embedding_scale_type, I8),
+        ("rotary_embedding_scale", rotary_embedding_scale, F32),
+        ("rotary_embedding_max_positions", rotary_embedding_max_positions, I32),
+        ("tp_size", tp_size, I32), ("tp_rank", tp_rank, I32), ("unfuse_qkv_gemm", 0, I8),
+        ("context_fmha_type", 0, I8), ("multi_block_mode", int(multi_block_mode), I8),
+        ("enable_xqa", int(enable_xqa), I8), ("kv_cache_quant_mode", kv_cache_quant_mode, I32),
+        ("remove_input_padding", int(remove_input_padding), I8), ("mask_type", 1, I32),
+        ("paged_kv_cache", int(paged_kv_cache), I32), ("tokens_per_block", tokens_per_block, I32),
+        ("type_id", str_dtype_to_trt(dtype), I32), ("max_context_length", max_context_length, I32),
+        ("qkv_bias_enabled", int(qkv_bias_enabled), I8), ("do_cross_attention", 0, I8), ("max_distance", 0, I32),
+        ("pos_shift_enabled", 0, I8), ("dense_context_fmha", 0, I8), ("use_paged_context_fmha", 0, I8),
+        ("use_cache", 1, I32), ("is_medusa_enabled", 0, I8),
+    ]
+    return Plugin("GPTAttention", fields)
+
+
+def gpt_attention(plugin, *, qkv, sequence_length, host_past_key_value_lengths, host_max_attention_window_sizes,
+                  host_sink_token_length, context_lengths, cache_indirection, host_request_types,
+                  kv_cache_block_pointers, host_kv_cache_block_pointers, kv_orig_quant_scale=None,
+                  kv_quant_orig_scale=None, host_context_lengths=None, qkv_bias=None):
+    """tensorrt_llm/functional.py:3487-3930 `gpt_attention` for a paged cache: assembles the plugin
+    input list in the order of gptAttentionPlugin.h:43-68 and enqueues.  Returns the context tensor."""
+    inputs = [qkv, sequence_length, host_past_key_value_lengths, host_max_attention_window_sizes,
+              host_sink_token_length, context_lengths, cache_indirection, host_request_types,
+              kv_cache_block_pointers, host_kv_cache_block_pointers]
+    if kv_orig_quant_scale is not None:
+        inputs += [kv_orig_quant_scale, kv_quant_orig_scale]
+    if host_context_lengths is not None:
+        inputs += [host_context_lengths]
+    if qkv_bias is not None:
+        inputs += [qkv_bias]
+    return plugin(*inputs, device=qkv.device)

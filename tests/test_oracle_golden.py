@@ -1,0 +1,213 @@
+"""Pin the CPU oracle against the known-answer vectors the reference itself spells out
+(SURVEY 8c): permutation maps, register relayouts, pack/unpack conventions, tolerances, fp8 scale KAT.
+CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+# cutlass_preprocessors.cpp:157-160 (mirrored in kernels/weightOnlyBatchedGemv/kernel.h:84-90,134-140)
+PERM_INT8 = [0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15]
+PERM_INT4 = [0, 1, 8, 9, 16, 17, 24, 25, 2, 3, 10, 11, 18, 19, 26, 27,
+             4, 5, 12, 13, 20, 21, 28, 29, 6, 7, 14, 15, 22, 23, 30, 31]
+
+
+def test_row_permutation_map_int8():
+    rows, cols = 32, 8
+    w = np.repeat(np.arange(rows, dtype=np.uint8)[:, None], cols, axis=1)  # every byte = its row index
+    out = oracle.permute_B_rows_for_mixed_gemm(w, rows, cols, oracle.INT8_W).reshape(rows, cols)
+    assert out[:16, 0].tolist() == PERM_INT8
+    assert out[16:, 0].tolist() == [16 + p for p in PERM_INT8]
+
+
+def test_row_permutation_map_int4():
+    rows, cols = 64, 8
+    vals = (np.arange(rows) % 16).astype(np.int8) - 8  # int4 can't hold 0..31: check via two passes
+    # use the group-local row index split into low/high 4 bits over two matrices
+    for shift in (0, 4):
+        idx = ((np.arange(rows) % 32) >> shift) & 0xF
+        unpacked = np.repeat(((idx ^ 8) - 8).astype(np.int8)[:, None], cols, axis=1)  # signed nibble with bits == idx
+        packed = oracle.pack_int8_tensor_to_packed_int4(unpacked)
+        out = oracle.permute_B_rows_for_mixed_gemm(packed, rows, cols, oracle.INT4_W).reshape(rows, cols // 2)
+        got = oracle.unpack_int4_packed_tensor_to_int8(out.view(np.int8))[:, 0].astype(np.int32) & 0xF
+        want = [(p >> shift) & 0xF for p in PERM_INT4] * 2
+        assert got.tolist() == want
+    del vals
+
+
+def test_register_relayout_int8():
+    # [e3 e2 e1 e0] -> [e3 e1 e2 e0] after +128 (cutlass_preprocessors.cpp:393-401)
+    w = np.array([0, 1, 2, 3, -128, -1, 127, 5], dtype=np.int8)
+    out = oracle.add_bias_and_interleave_int8s(w)
+    assert out.tolist() == [128, 130, 129, 131, 0, 255, 127, 133]
+
+
+def test_register_relayout_int4():
+    # [e7 .. e0] -> [e7 e5 e3 e1 e6 e4 e2 e0] after +8 (cutlass_preprocessors.cpp:434-441)
+    elts = np.array([-8, -7, -6, -5, -4, -3, -2, -1], dtype=np.int8)  # +8 -> 0..7
+    packed = oracle.pack_int8_tensor_to_packed_int4(elts[None, :])
+    out = oracle.add_bias_and_interleave_int4s(packed)
+    word = int(out.view(np.uint32).ravel()[0])
+    nibbles = [(word >> (4 * i)) & 0xF for i in range(8)]
+    assert nibbles == [0, 2, 4, 6, 1, 3, 5, 7]
+
+
+def test_pack_unpack_convention():
+    # low nibble = even element, sign extension (weightOnlyQuantOp.cpp:296-302)
+    packed = np.array([[0x8F, 0x70, 0x1E]], dtype=np.uint8).view(np.int8)
+    assert oracle.unpack_int4_packed_tensor_to_int8(packed).tolist() == [[-1, -8, 0, 7, -2, 1]]
+    rt = oracle.pack_int8_tensor_to_packed_int4(oracle.unpack_int4_packed_tensor_to_int8(packed))
+    assert (rt == packed).all()
+    with pytest.raises(ValueError):
+        oracle.pack_int8_tensor_to_packed_int4(np.array([[8, 0]], dtype=np.int8))
+
+
+def test_interleave_description_int4():
+    # kernel.h:71-79: with interleave 4 and 64-row tiles, 4 adjacent columns' 64-row tiles alternate
+    rows, cols = 128, 8
+    # column-major input where every element of column c, row-tile t carries the tag (c, t)
+    cm = np.zeros((cols, rows), dtype=np.int8)
+    for c in range(cols):
+        for r in range(rows):
+            cm[c, r] = (c % 4) * 2 + (r // 64) - 8  # 0..7 tags as signed nibbles
+    packed = oracle.pack_int8_tensor_to_packed_int4(cm)
+    out = oracle.interleave_column_major_tensor(packed, rows, cols, oracle.INT4_W)
+    got = oracle.unpack_int4_packed_tensor_to_int8(out.view(np.int8).reshape(cols // 4, -1)) + 8
+    # one "row" of the interleaved tensor = 4 columns x 128 rows: tile0 of c0..c3, then tile1 of c0..c3
+    want = np.repeat(np.array([0, 2, 4, 6, 1, 3, 5, 7]), 64)
+    assert (got[0] == want).all() and (got[1] == want).all()
+
+
+def test_preprocess_pipeline_is_composition_and_sm90_is_transpose():
+    rng = np.random.default_rng(0)
+    K, N = 128, 64
+    for qt in (oracle.INT8_W, oracle.INT4_W):
+        bits = 8 if qt == oracle.INT8_W else 4
+        w = rng.integers(-128, 128, size=(K, N * bits // 8), dtype=np.int8)
+        full = oracle.preprocess_weights_for_mixed_gemm(w, qt, arch=80)
+        a = oracle.permute_B_rows_for_mixed_gemm(w, K, N, qt)
+        b = oracle.subbyte_transpose(a, K, N, qt)
+        c = oracle.interleave_column_major_tensor(b, K, N, qt)
+        d = (oracle.add_bias_and_interleave_int8s if qt == oracle.INT8_W else oracle.add_bias_and_interleave_int4s)(c)
+        assert (full.view(np.uint8).ravel() == d.ravel()).all()
+        sm90 = oracle.preprocess_weights_for_mixed_gemm(w, qt, arch=90)
+        if qt == oracle.INT8_W:
+            assert (sm90.reshape(N, K) == w.T).all()
+        else:
+            un = oracle.unpack_int4_packed_tensor_to_int8(w)
+            assert (oracle.unpack_int4_packed_tensor_to_int8(sm90.reshape(N, K // 2)) == un.T).all()
+
+
+def test_symmetric_quantize_known_answers():
+    # cutlass_preprocessors.cpp:646-717: scale = absmax / 2^(bits-1); round half away; clip
+    w = torch.tensor([[1.0, -2.0], [0.5, 2.0], [-1.0, 0.25], [0.0625, -0.75]] * 16)  # [64, 2] -> pad cols
+    w = torch.cat([w] * 32, dim=1)  # [64, 64]
+    q8, s8 = oracle.symmetric_quantize(w, oracle.INT8_W)
+    assert s8[0].item() == 1.0 / 128 and s8[1].item() == 2.0 / 128
+    assert q8[0, 0] == 127 and q8[0, 1] == -128 and q8[1, 0] == 64 and q8[2, 0] == -128 and q8[3, 0] == 8
+    q4, s4 = oracle.symmetric_quantize(w, oracle.INT4_W)
+    u4 = oracle.unpack_int4_packed_tensor_to_int8(q4)
+    assert s4[0].item() == 1.0 / 8 and u4[0, 0] == 7 and u4[0, 1] == -8 and u4[1, 0] == 4 and u4[3, 0] == 1  # 0.5 -> 1
+
+
+def test_fp8_scale_known_answers():
+    # tests/quantization/test_fp8_quantization.py:45-80: A=[[1,2,3],[2,4,6]]
+    a = torch.tensor([[1, 2, 3], [2, 4, 6]], dtype=torch.float32)
+    q, s = oracle.quantize_e4m3(a, "activation")
+    assert torch.equal(s, torch.tensor([[3.0], [6.0]]) / 448.0)
+    q, s = oracle.quantize_e4m3(a, "weight")
+    assert torch.equal(s, torch.tensor([[2.0, 4.0, 6.0]]) / 448.0)
+    q, s = oracle.quantize_e4m3(a, "per_tensor")
+    assert torch.equal(s, torch.tensor([[6.0]]) / 448.0)
+    # exact round trip on small integers whose row max is 7 (scale = 1/64), :117-123
+    torch.manual_seed(42)
+    b = torch.randint(0, 8, (16, 64)).float()
+    b[:, 0] = 7
+    qb, sb = oracle.quantize_e4m3(b, "activation")
+    assert torch.equal(qb.float() * sb, b)
+    assert oracle.fp8_scale(0.0) == np.float32(1.0 / (448 * 512))  # cudaFp8Utils.cu:215
+
+
+def test_woq_tolerance_formula():
+    ref = torch.tensor([[-4.0, 2.0]])
+    assert oracle.woq_tolerance(ref, oracle.INT4_W) == 4.0 / 8 * 1.5      # _utils.py:99-109
+    assert oracle.woq_tolerance(ref, oracle.INT8_W) == 4.0 / 128 * 1.5
+    assert oracle.woq_tolerance(ref, oracle.INT4_W, torch.bfloat16) == 4.0 / 8 * 1.5 * 3
+
+
+def test_dequant_single_vs_double_rounding():
+    torch.manual_seed(0)
+    K, N, g = 128, 64, 64
+    q = np.random.default_rng(1).integers(-8, 8, size=(K, N), dtype=np.int8)
+    for dt in (torch.float16, torch.bfloat16):
+        scale = torch.rand(K // g, N, dtype=dt)
+        zero = torch.randn(K // g, N, dtype=dt)
+        w1 = oracle.dequant_fma(q, scale, zero, g)
+        w2 = oracle.dequant_torch(q, scale, zero, g)
+        # torch's own two-rounding reference (test_weight_only_groupwise_quant_matmul.py:190-195)
+        ref = torch.from_numpy(q).to(dt) * scale.repeat_interleave(g, 0) + zero.repeat_interleave(g, 0)
+        assert torch.equal(w2, ref)
+        # the two definitions differ by at most one rounding of the intermediate q*scale
+        qs = (torch.from_numpy(q).float() * scale.float().repeat_interleave(g, 0)).abs()
+        ulp = torch.finfo(dt).eps * torch.maximum(qs, ref.float().abs()).clamp_min(1e-3)
+        assert ((w1.float() - ref.float()).abs() <= ulp).all()
+        # scale-only: both definitions coincide exactly (one rounding of an exact product)
+        assert torch.equal(oracle.dequant_fma(q, scale, None, g), torch.from_numpy(q).to(dt) * scale.repeat_interleave(g, 0))
+
+
+def test_smooth_quant_reference_matches_torch_formula():
+    # tests/quantization/_utils.py:112-142 on the reference's own small shape family
+    torch.manual_seed(0)
+    m, n, k = 32, 96, 64
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+    b = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+    sa = torch.randint(1, 10, (m, 1)).float() * 1e-2
+    sb = torch.randint(1, 10, (1, n)).float() * 1e-2
+    for dt in (torch.float16, torch.float32, torch.int32):
+        out, acc = oracle.smooth_quant_gemm(a.numpy(), b.numpy(), sa.numpy(), sb.numpy(), True, True, dt)
+        ref_acc = a.to(torch.int32) @ b.to(torch.int32).t()
+        assert (torch.from_numpy(acc) == ref_acc).all()
+        ref = ref_acc.float() * (sa @ sb)
+        ref = torch.round(ref).to(dt) if dt == torch.int32 else ref.to(dt)
+        assert torch.equal(out, ref)
+
+
+def test_quantize_per_token_matches_torch_reference():
+    # _utils.py:145-150 (x*127/max).round().clip  vs kernel order x*(127/max): equal up to ties
+    torch.manual_seed(0)
+    x = torch.randn(8, 256, dtype=torch.float16)
+    q, s = oracle.quantize_per_token(x)
+    xf = x.float()
+    xmax = xf.abs().amax(-1, keepdim=True)
+    ref = (xf * 127.0 / xmax).round().clip(-128, 127).to(torch.int8)
+    assert (np.abs(q.astype(np.int32) - ref.numpy().astype(np.int32)) <= 1).all()
+    assert (q == ref.numpy()).mean() > 0.999
+    assert np.allclose(s, (xmax / 127.0).numpy(), rtol=1e-6)
+
+
+def test_decode_attention_reference_against_plain_softmax():
+    # the oracle equals softmax(q K^T / sqrt(d)) V up to the +1e-6 in the denominator
+    torch.manual_seed(42)
+    B, Hq, Hkv, D, tpb = 2, 4, 2, 64, 16
+    seq = [5, 37]
+    cache = oracle.PagedKVCache(B, Hkv, D, 64, tpb, torch.float16)
+    for b in range(B):
+        for t in range(seq[b] - 1):
+            for h in range(Hkv):
+                cache.write(b, 0, h, t, torch.randn(D).half())
+                cache.write(b, 1, h, t, torch.randn(D).half())
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D).half()
+    out = oracle.decode_attention(qkv, cache, seq, Hq, Hkv, D)
+    for b in range(B):
+        k_new = qkv[b, Hq * D:(Hq + Hkv) * D].reshape(Hkv, D)
+        v_new = qkv[b, (Hq + Hkv) * D:].reshape(Hkv, D)
+        for h in range(Hq):
+            hk = h // (Hq // Hkv)
+            # cache was updated in place by the oracle: position seq-1 now holds the new token
+            K = cache.gather(b, 0, hk, seq[b]).float()
+            V = cache.gather(b, 1, hk, seq[b]).float()
+            assert torch.equal(K[-1], k_new[hk].float()) and torch.equal(V[-1], v_new[hk].float())
+            p = torch.softmax((K @ qkv[b, h * D:(h + 1) * D].float()) / D ** 0.5, 0)
+            ref = p @ V
+            assert torch.allclose(out[b, h * D:(h + 1) * D].float(), ref, atol=2e-3)
