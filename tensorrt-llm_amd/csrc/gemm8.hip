@@ -10,6 +10,8 @@
 // A is [M, K] row-major, B is [N, K] row-major (smoothQuantGemmPlugin.cpp:224-230), so both MFMA
 // operands are K-contiguous: a lane's fragment is 16 (int8) or 8 (fp8) consecutive bytes of a row.
 #include "kernels.h"
+#include <cmath>
+#include <cstdlib>
 
 namespace mi355q
 {
@@ -200,6 +202,203 @@ __global__ __launch_bounds__(256) void gemm8_kernel(Gemm8Args g)
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-tile path: TM x TN output tile, K-tile of 128 bytes, LDS double buffer filled by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave-instruction), XOR-swizzled 16-byte
+// chunks (chunk ^= row & 7: conflict-free ds_read_b128 of 16 rows x one chunk; the swizzle is
+// applied to the per-lane SOURCE address, the LDS image of one DMA stays lane-linear),
+// v_mfma_i32_16x16x64_i8.  The weight tile is the MFMA A operand and the activation tile the B
+// operand, so a lane ends up with 4 consecutive output columns (n) of one row (m): 8-byte stores.
+// Requires m % TM == 0, n % TN == 0, k % 128 == 0 (other shapes take the 128 x 128 kernel above).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm8_big_kernel(Gemm8Args g, int tiles_m, int tiles_n)
+{
+    constexpr int NWAVES = WM * WN;
+    constexpr int TK = 128;
+    constexpr int WTM = TM / WM, WTN = TN / WN; // wave tile
+    constexpr int MT = WTM / 16, NT = WTN / 16; // 16 x 16 MFMA tiles per wave
+    constexpr int A_BYTES = TM * TK, B_BYTES = TN * TK;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int DMA_PER_TILE = BUF_BYTES / 1024;      // wave-instructions per K-tile
+    constexpr int DMA_PER_WAVE = DMA_PER_TILE / NWAVES;
+    static_assert(DMA_PER_TILE % NWAVES == 0, "tile does not split evenly over the waves");
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF_BYTES]; // the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware remap (blocks b and b+8 share an XCD's L2): give each XCD a contiguous run of tiles,
+    // walked n-fastest inside panels of 8 m-tiles so neighbours share activation / weight panels.
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const size_t m0 = (size_t) tm * TM, n0 = (size_t) tn * TN;
+
+    // LDS-DMA bookkeeping: DMA i of this wave covers rows [8*(wave*DMA_PER_WAVE+i), +8) of the
+    // concatenated (A rows, then B rows) image; lane -> (row = l/8, stored chunk = l%8)
+    const int drow = lane >> 3, dchunk = lane & 7;
+    const uint8_t* src[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i)
+    {
+        const int row = (wave * DMA_PER_WAVE + i) * 8 + drow; // 0 .. TM+TN-1
+        const int chunk = dchunk ^ (row & 7);                  // source chunk stored at dchunk
+        src[i] = row < TM ? g.A + (m0 + row) * (size_t) g.k + chunk * 16
+                          : g.B + (n0 + (row - TM)) * (size_t) g.k + chunk * 16;
+    }
+    auto stage = [&](int kt, int buf)
+    {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i)
+        {
+            uint8_t* dst = lds + buf * BUF_BYTES + (wave * DMA_PER_WAVE + i) * 1024;
+            __builtin_amdgcn_global_load_lds(
+                (gbl_void_t*) (src[i] + (size_t) kt * TK), (lds_void_t*) dst, 16, 0, 0);
+        }
+    };
+
+    i32x4_t acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            acc[i][j] = i32x4_t{0, 0, 0, 0};
+
+    // fragment addressing: lane l -> row (l & 15) of its 16-row tile, 16-byte k-chunk (l >> 4) + 4*ks
+    const int frow = lane & 15, fk = lane >> 4;
+    const int nk = g.k / TK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt)
+    {
+        const int buf = kt & 1;
+        if (kt + 1 < nk)
+            stage(kt + 1, buf ^ 1);
+        const uint8_t* sa = lds + buf * BUF_BYTES;           // activation rows (m)
+        const uint8_t* sb = sa + A_BYTES;                    // weight rows (n)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+        {
+            i32x4_t fw[NT], fa[MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+            {
+                const int row = wn * WTN + i * 16 + frow;
+                fw[i] = *reinterpret_cast<const i32x4_t*>(sb + row * TK + (((ks * 4 + fk) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+            {
+                const int row = wm * WTM + j * 16 + frow;
+                fa[j] = *reinterpret_cast<const i32x4_t*>(sa + row * TK + (((ks * 4 + fk) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
+    const int em = lane & 15, en = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+    {
+        const size_t row = m0 + wm * WTM + j * 16 + em;
+        const float sr = g.alpha_row[g.per_token ? row : 0];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+        {
+            const size_t col = n0 + wn * WTN + i * 16 + en;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = (float) acc[i][j][r] * (g.alpha_col[g.per_channel ? col + r : 0] * sr);
+            const size_t idx = row * g.n + col;
+            switch (g.out_type)
+            {
+            case MI355Q_HALF:
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
+                    = make_uint2(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]));
+                break;
+            case MI355Q_BF16:
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
+                    = make_uint2(pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3]));
+                break;
+            case MI355Q_FLOAT:
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+                break;
+            default:
+                *reinterpret_cast<int4*>(reinterpret_cast<int32_t*>(g.C) + idx)
+                    = make_int4((int) rintf(v[0]), (int) rintf(v[1]), (int) rintf(v[2]), (int) rintf(v[3]));
+                break;
+            }
+        }
+    }
+}
+
+// Tile choice: fewest "rounds" of the 256 CUs weighted by how efficient each tile shape runs.
+struct BigTile
+{
+    int tm, tn, blocks_per_cu;
+    float eff;
+};
+
+template <int TM, int TN, int WM, int WN>
+void launch_big(const Gemm8Args& g, hipStream_t stream)
+{
+    const int tiles_m = g.m / TM, tiles_n = g.n / TN;
+    hipLaunchKernelGGL((gemm8_big_kernel<TM, TN, WM, WN>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, stream, g,
+        tiles_m, tiles_n);
+}
+
+bool try_launch_big_int8(const Gemm8Args& g, hipStream_t stream)
+{
+    if (g.k % 128 != 0 || g.m % 128 != 0 || g.n % 128 != 0)
+        return false;
+    const BigTile cand[3] = {{256, 256, 1, 1.00f}, {256, 128, 1, 0.92f}, {128, 128, 2, 0.80f}};
+    int best = -1;
+    double best_cost = 1e30;
+    for (int c = 0; c < 3; ++c)
+    {
+        if (g.m % cand[c].tm || g.n % cand[c].tn)
+            continue;
+        const double tiles = (double) (g.m / cand[c].tm) * (g.n / cand[c].tn);
+        const double rounds = std::ceil(tiles / (256.0 * cand[c].blocks_per_cu));
+        const double cost = rounds * cand[c].blocks_per_cu * cand[c].tm * cand[c].tn / cand[c].eff;
+        if (cost < best_cost)
+        {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    const char* force = getenv("MI355Q_GEMM8_TILE"); // debug / measurement override: 0, 1, 2
+    if (force && force[0] >= '0' && force[0] <= '2' && g.m % cand[force[0] - '0'].tm == 0
+        && g.n % cand[force[0] - '0'].tn == 0)
+        best = force[0] - '0';
+    switch (best)
+    {
+    case 0: launch_big<256, 256, 2, 4>(g, stream); return true;
+    case 1: launch_big<256, 128, 4, 2>(g, stream); return true;
+    case 2: launch_big<128, 128, 2, 2>(g, stream); return true;
+    default: return false;
+    }
+}
+
 // ---- per-token int8 quantisation: one wave per row (kernels/quantization.cu:93-127)
 template <typename T>
 __device__ __forceinline__ float load_as_float(const void* src, size_t i);
@@ -349,8 +548,11 @@ void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel,
         return;
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, alphaCol, alphaRow,
         per_token, per_channel, m, n, k, out_type};
-    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm8_kernel<false>), grid, dim3(256), 0, stream, g);
+    if (!try_launch_big_int8(g, stream))
+    {
+        dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+        hipLaunchKernelGGL((gemm8_kernel<false>), grid, dim3(256), 0, stream, g);
+    }
     MQ_HIP(hipGetLastError());
 }
 
