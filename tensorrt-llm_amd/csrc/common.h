@@ -164,10 +164,23 @@ struct T16<f16_t>
     }
 };
 
+// two floats -> one dword of two 16-bit values (a in the low half), RNE: a single
+// v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950
 template <typename T>
-__device__ __forceinline__ uint32_t pack2(float a, float b)
+__device__ __forceinline__ uint32_t pack2(float a, float b);
+template <>
+__device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b)
 {
-    return (uint32_t) T16<T>::from_float(a) | ((uint32_t) T16<T>::from_float(b) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+}
+template <>
+__device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b)
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, f16x2_));
 }
 
 } // namespace mi355q

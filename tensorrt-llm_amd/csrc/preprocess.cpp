@@ -79,36 +79,43 @@ struct Sm80Map
     }
 };
 
-// ---- GFX950: MFMA-fragment-major tiles of 1 KiB = 64 lanes x 16 B.
-//   n-block = 32 columns, k-tile = 64 rows (int4) / 32 rows (int8); the k-tiles of an n-block are
-//   contiguous.  Lane l = h*16 + c of a tile owns column c of each 16-column half t and the 8
-//   consecutive k = 8h..8h+7 of each 32-row k-step s -- exactly the B operand fragment of
-//   v_mfma_f32_16x16x32_{bf16,f16} -- so one global_load_dwordx4 per lane feeds 4 (int4) or
-//   2 (int8) MFMAs with no shuffle.  Values stay signed two's complement (no bias).
-//   int4: dword (t*2 + s), nibble j  <->  k = kt*64 + s*32 + 8h + j,        n = nb*32 + t*16 + c
-//   int8: dword (t*2 + j/4), byte j%4 <-> k = kt*32 + 8h + j,               n = nb*32 + t*16 + c
+// ---- GFX950: MFMA-fragment-major tiles.
+//   n-block = 16 columns; the k-tiles of an n-block are contiguous ("tile run").
+//   int4: k-tile = 128 rows = 1 KiB = 64 lanes x 16 B.  Lane l = h*16 + c owns column c and, in
+//         dword s (k-step s of 32 rows), the 8 consecutive rows k = 8h .. 8h+7 as nibbles 0..7 --
+//         exactly the B operand fragment of v_mfma_f32_16x16x32_{bf16,f16}: one
+//         global_load_dwordx4 per lane feeds 4 MFMAs with no shuffle.  When K % 128 == 64 the run
+//         ends with a 512-byte half tile (64 rows: lane l owns 8 B at l*8, dwords s = 0, 1).
+//   int8: k-tile = 64 rows = 1 KiB.  Lane l owns dwords (s*2 + j/4), byte j%4 for k-step s = 0, 1.
+//   Values stay signed two's complement (no bias); byte count == the row-major tensor's.
 struct Gfx950Map
 {
     int bits;
-    size_t K, N, ktile, ktiles;
+    size_t K, N, run_bytes;
     explicit Gfx950Map(const Geometry& g)
         : bits(g.bits)
         , K(g.K)
         , N(g.N)
     {
-        ktile = bits == 4 ? 64 : 32;
-        ktiles = K / ktile;
+        run_bytes = K * 16 * bits / 8; // one n-block: K rows x 16 columns
     }
     size_t slot(size_t k, size_t n) const
     {
-        size_t nb = n / 32, t = (n % 32) / 16, c = n % 16;
-        size_t kt = k / ktile, r = k % ktile;
-        size_t s = r / 32, h = (r % 32) / 8, j = r % 8;
-        size_t lane = h * 16 + c;
-        size_t byte = ((nb * ktiles + kt) * 64 + lane) * 16;
+        const size_t nb = n / 16, c = n % 16;
+        const size_t base = nb * run_bytes;
         if (bits == 4)
-            return (byte + (t * 2 + s) * 4) * 2 + j;
-        return byte + (t * 2 + j / 4) * 4 + j % 4;
+        {
+            const size_t kt = k / 128, r = k % 128;
+            const size_t s = r / 32, h = (r % 32) / 8, j = r % 8;
+            const size_t lane = h * 16 + c;
+            const bool half = kt == K / 128; // trailing 64-row half tile
+            const size_t byte = base + kt * 1024 + (half ? lane * 8 : lane * 16) + s * 4;
+            return byte * 2 + j;
+        }
+        const size_t kt = k / 64, r = k % 64;
+        const size_t s = r / 32, h = (r % 32) / 8, j = r % 8;
+        const size_t lane = h * 16 + c;
+        return base + kt * 1024 + lane * 16 + (s * 2 + j / 4) * 4 + j % 4;
     }
 };
 
@@ -134,7 +141,7 @@ void check_shape(const size_t shape[3], int weight_type, int layout)
             "Number of bytes for rows and cols must be a multiple of 32 (K=%zu N=%zu)", K, N);
         break;
     case MI355Q_LAYOUT_GFX950:
-        MQ_CHECK(K % 64 == 0 && N % 32 == 0, "GFX950 layout needs K %% 64 == 0 and N %% 32 == 0 (K=%zu N=%zu)", K, N);
+        MQ_CHECK(K % 64 == 0 && N % 16 == 0, "GFX950 layout needs K %% 64 == 0 and N %% 16 == 0 (K=%zu N=%zu)", K, N);
         break;
     default: MQ_CHECK(false, "unknown layout %d", layout);
     }

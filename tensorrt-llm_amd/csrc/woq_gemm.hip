@@ -3,18 +3,23 @@
 //   kernels/weightOnlyBatchedGemv/{kernel.h,kernelLauncher.cu}  (m < 5, CUDA cores) and
 //   kernels/cutlass_kernels/fpA_intB_gemm/*                      (m >= 5, dequant-in-mainloop)
 // of the reference with one gfx950 design:
-//   * weights live in the GFX950 layout (preprocess.cpp): 1 KiB tiles, one 16-byte load per lane
-//     is already the B fragment of v_mfma_f32_16x16x32 for 32 columns -- no LDS, no shuffles;
+//   * weights live in the GFX950 layout (preprocess.cpp): 1 KiB tiles of 16 columns x 128 (int4) or
+//     64 (int8) rows; one 16-byte load per lane is already the B fragment of 4 (2) consecutive
+//     v_mfma_f32_16x16x32 k-steps -- no LDS, no shuffles;
 //   * dequantisation in registers with the reference's single-rounding semantic
 //     w = round16(fma(q, scale, zero)) (kernel.h:364-365, mma_tensorop_dequantizer.h:244-252):
-//     v_cvt_f32_i32 (SDWA sign-extending byte select) + v_fma_f32 + v_cvt_pk_{bf16,f16}_f32;
+//     v_cvt_f32_i32 (SDWA sign-extending byte select) + v_pk_fma_f32 + v_cvt_pk_{bf16,f16}_f32;
 //     the same device function backs mi355q_weight_only_dequantize, i.e. the bit-exact gate checks
 //     exactly the values the MFMA consumes;
-//   * small m (decode): one workgroup = one 32-column n-block, 8 waves split K, fp32 MFMA
-//     accumulators reduced through LDS -- HBM-bound streaming of the weight tiles;
+//   * decode (m <= 16 per block row): one workgroup = one 16-column n-block, 4 waves split K in
+//     chunks of 4 tiles; every wave issues a whole chunk (4 KiB of weights + activations + scales)
+//     as one burst of branch-free loads and keeps the next chunk in flight while it dequantises;
+//     fp32 MFMA accumulators are reduced through LDS.  The launch is HBM/VALU co-limited: the
+//     dequant costs ~2.8 VALU instructions per weight, so all 256 CUs must take part (N/16 blocks);
 //   * optional split-K across workgroups (fp32 slabs in the workspace + a tiny reduce kernel) when
-//     N/32 workgroups cannot fill the chip.
+//     N/16 workgroups cannot fill the chip.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mi355q
 {
@@ -26,11 +31,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int GEMV_WAVES = 8;
+constexpr int GEMV_WAVES = 4;
+constexpr int GEMV_CH = 4; // k-tiles per chunk
 
 struct WoqArgs
 {
-    const uint4* qweight;
+    const uint8_t* qweight;
     const uint16_t* scales;
     const uint16_t* zeros;
     const uint16_t* act;
@@ -38,8 +44,8 @@ struct WoqArgs
     uint16_t* out;
     float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1
     int m, n, k;
-    int group; // group size in k; == k for per-channel
-    int ktiles; // k / KTILE
+    int group;  // group size in k; == k for per-channel
+    int ktiles; // full k-tiles: k / KTILE
     int ksplit;
 };
 
@@ -90,105 +96,192 @@ __device__ __forceinline__ uint4 dequant8_int8(uint32_t w0, uint32_t w1, float s
     return r;
 }
 
-// Dequantise one 1 KiB tile's lane fragment.  frag[t][s]: n-half t (16 columns), k-step s (32 rows).
-// int4: KTILE = 64 (2 k-steps); int8: KTILE = 32 (1 k-step, frag[t][0] only).
-template <typename T, int WBITS, bool ZERO>
-__device__ __forceinline__ void dequant_tile(
-    const uint4& w, const WoqArgs& a, int kt, int n0, int lane, uint4 (&frag)[2][2])
+template <int WBITS>
+struct Geo
 {
-    constexpr int KTILE = WBITS == 4 ? 64 : 32;
-    const int c = lane & 15;
-    const int g = (kt * KTILE) / a.group; // a tile never straddles a group (group % 64 == 0)
+    static constexpr int KTILE = WBITS == 4 ? 128 : 64;
+    static constexpr int KSTEPS = KTILE / 32;      // MFMA k-steps per tile (4 or 2)
+    static constexpr int NSZ = WBITS == 4 ? 2 : 1; // (scale, zero) pairs a tile may span (group 64 on int4)
+};
+
+// k-step ST of the lane fragment `w` -> dequantised B operand.  s / z: this k-step's group.
+template <typename T, int WBITS, int ST>
+__device__ __forceinline__ uint4 dequant_step(const uint4& w, float s, float z)
+{
     const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w);
+    if constexpr (WBITS == 4)
+        return dequant8_int4<T>(wd[ST], s * 0.0625f, z);
+    else
+        return dequant8_int8<T>(wd[ST * 2], wd[ST * 2 + 1], s, z);
+}
+
+__device__ __forceinline__ uint4 load_nt(const uint4* p)
+{
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Everything one wave needs for CH consecutive k-tiles of its n-block, issued as one burst of
+// independent, BRANCH-FREE loads (clamped addresses, so the compiler keeps the next chunk in flight
+// behind a counted vmcnt while this one is computed).  Weights: CH KiB contiguous per wave,
+// nontemporal (streamed once); activations and scales come from L2.
+template <int WBITS, int CH>
+struct GemvChunk
+{
+    uint4 w[CH];
+    uint4 a[CH][Geo<WBITS>::KSTEPS];
+    uint16_t s[CH][Geo<WBITS>::NSZ], z[CH][Geo<WBITS>::NSZ];
+};
+
+template <typename T, int WBITS, bool ZERO, int CH>
+__device__ __forceinline__ void gemv_load_chunk(GemvChunk<WBITS, CH>& c, const WoqArgs& a, const uint4* wbase,
+    const uint16_t* arow, int kt0, int kt_last, int col)
+{
+    constexpr int KTILE = Geo<WBITS>::KTILE;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < CH; ++i)
     {
-        const size_t si = (size_t) g * a.n + n0 + t * 16 + c;
-        const float s = T16<T>::to_float(a.scales[si]);
-        const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
-        if constexpr (WBITS == 4)
+        const int kt = min(kt0 + i, kt_last); // tiles past the end re-read the last one; zeroed in compute
+        c.w[i] = load_nt(wbase + (size_t) kt * 64);
+#pragma unroll
+        for (int st = 0; st < Geo<WBITS>::KSTEPS; ++st)
+            c.a[i][st] = *reinterpret_cast<const uint4*>(arow + (size_t) kt * KTILE + st * 32);
+#pragma unroll
+        for (int h = 0; h < Geo<WBITS>::NSZ; ++h)
         {
-            frag[t][0] = dequant8_int4<T>(wd[t * 2 + 0], s * 0.0625f, z);
-            frag[t][1] = dequant8_int4<T>(wd[t * 2 + 1], s * 0.0625f, z);
-        }
-        else
-        {
-            frag[t][0] = dequant8_int8<T>(wd[t * 2 + 0], wd[t * 2 + 1], s, z);
+            const int g = (kt * KTILE + h * 64) / a.group;
+            const size_t si = (size_t) g * a.n + col;
+            c.s[i][h] = a.scales[si];
+            c.z[i][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
         }
     }
 }
 
-// grid: x = n-block (32 columns), y = 16-row chunk of m, z = k split.  block = 8 waves.
+template <typename T, int WBITS, int ST>
+__device__ __forceinline__ f32x4_t gemv_step(const uint4& w, const uint4& av, float s, float z, f32x4_t acc)
+{
+    return mfma16<T>(av, dequant_step<T, WBITS, ST>(w, s, z), acc);
+}
+
+template <typename T, int WBITS, int CH>
+__device__ __forceinline__ void gemv_compute_chunk(const GemvChunk<WBITS, CH>& c, f32x4_t& acc, int kt0, int kt_end)
+{
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+    {
+        const bool live = kt0 + i < kt_end; // wave-uniform; a dead tile gets scale = zero = 0 -> W = 0
+        float s[2], z[2];
+#pragma unroll
+        for (int h = 0; h < Geo<WBITS>::NSZ; ++h)
+        {
+            s[h] = live ? T16<T>::to_float(c.s[i][h]) : 0.f;
+            z[h] = live ? T16<T>::to_float(c.z[i][h]) : 0.f;
+        }
+        if constexpr (WBITS == 4)
+        {
+            acc = gemv_step<T, 4, 0>(c.w[i], c.a[i][0], s[0], z[0], acc);
+            acc = gemv_step<T, 4, 1>(c.w[i], c.a[i][1], s[0], z[0], acc);
+            acc = gemv_step<T, 4, 2>(c.w[i], c.a[i][2], s[1], z[1], acc);
+            acc = gemv_step<T, 4, 3>(c.w[i], c.a[i][3], s[1], z[1], acc);
+        }
+        else
+        {
+            acc = gemv_step<T, 8, 0>(c.w[i], c.a[i][0], s[0], z[0], acc);
+            acc = gemv_step<T, 8, 1>(c.w[i], c.a[i][1], s[0], z[0], acc);
+        }
+    }
+}
+
+// grid: x = n-block (16 columns), y = 16-row chunk of m, z = k split.  block = 4 waves; wave w owns
+// the chunks w, w+4, ... (CH k-tiles each) of the block's k range (ping-pong register sets).
 template <typename T, int WBITS, bool ZERO>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
-    constexpr int KTILE = WBITS == 4 ? 64 : 32;
-    constexpr int KSTEPS = KTILE / 32;
-    __shared__ float red[GEMV_WAVES][2][64][4];
+    constexpr int CH = GEMV_CH;
+    constexpr int KTILE = Geo<WBITS>::KTILE;
+    __shared__ float red[GEMV_WAVES][64][4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = blockIdx.x;
     const int m0 = blockIdx.y * 16;
-    const int n0 = nb * 32;
-    const int row = m0 + (lane & 15);
+    const int col = nb * 16 + (lane & 15);
     const int kh = (lane >> 4) * 8;
 
     const int per = (a.ktiles + a.ksplit - 1) / a.ksplit;
     const int kt_begin = blockIdx.z * per;
     const int kt_end = min(a.ktiles, kt_begin + per);
+    const int kt_last = max(kt_end - 1, 0);
 
-    const uint4* wbase = a.qweight + (size_t) nb * a.ktiles * 64 + lane;
-    const uint16_t* arow = a.act + (size_t) row * a.k + kh;
-    const bool row_ok = row < a.m;
+    const size_t run_bytes = (size_t) a.k * 16 * WBITS / 8;
+    const uint8_t* run = a.qweight + (size_t) nb * run_bytes;
+    const uint4* wbase = reinterpret_cast<const uint4*>(run) + lane;
+    // rows >= m are clamped to row m-1: their MFMA output rows are computed but never stored
+    const uint16_t* arow = a.act + (size_t) min(m0 + (lane & 15), a.m - 1) * a.k + kh;
 
-    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-    for (int kt = kt_begin + wave; kt < kt_end; kt += GEMV_WAVES)
+    constexpr int STRIDE = GEMV_WAVES * CH;
+    GemvChunk<WBITS, CH> ca, cb;
+    int kt0 = kt_begin + wave * CH;
+    if (kt0 < kt_end)
     {
-        const uint4 w = wbase[(size_t) kt * 64];
-        uint4 af[KSTEPS];
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+        gemv_load_chunk<T, WBITS, ZERO, CH>(ca, a, wbase, arow, kt0, kt_last, col);
+        while (true)
         {
-            af[s] = make_uint4(0, 0, 0, 0);
-            if (row_ok)
-                af[s] = *reinterpret_cast<const uint4*>(arow + (size_t) kt * KTILE + s * 32);
+            // invariant: `ca` holds chunk kt0
+            const bool more_b = kt0 + STRIDE < kt_end;
+            if (more_b)
+                gemv_load_chunk<T, WBITS, ZERO, CH>(cb, a, wbase, arow, kt0 + STRIDE, kt_last, col);
+            gemv_compute_chunk<T, WBITS, CH>(ca, acc, kt0, kt_end);
+            if (!more_b)
+                break;
+            kt0 += STRIDE;
+            const bool more_a = kt0 + STRIDE < kt_end;
+            if (more_a)
+                gemv_load_chunk<T, WBITS, ZERO, CH>(ca, a, wbase, arow, kt0 + STRIDE, kt_last, col);
+            gemv_compute_chunk<T, WBITS, CH>(cb, acc, kt0, kt_end);
+            if (!more_a)
+                break;
+            kt0 += STRIDE;
         }
-        uint4 frag[2][2];
-        dequant_tile<T, WBITS, ZERO>(w, a, kt, n0, lane, frag);
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-        {
-            acc0 = mfma16<T>(af[s], frag[0][s], acc0);
-            acc1 = mfma16<T>(af[s], frag[1][s], acc1);
-        }
+    }
+
+    // int4 with K % 128 == 64: the run ends with a 512-byte half tile (2 k-steps); wave 0 of the
+    // last k split takes it
+    if (WBITS == 4 && (a.k & 127) && blockIdx.z == a.ksplit - 1 && wave == 0)
+    {
+        const int kbase = a.ktiles * KTILE;
+        const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) a.ktiles * 1024 + lane * 8);
+        const size_t si = (size_t) (kbase / a.group) * a.n + col;
+        const float s = T16<T>::to_float(a.scales[si]);
+        const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
+        const uint4 w = make_uint4(hw.x, hw.y, 0, 0);
+        acc = gemv_step<T, 4, 0>(w, *reinterpret_cast<const uint4*>(arow + kbase), s, z, acc);
+        acc = gemv_step<T, 4, 1>(w, *reinterpret_cast<const uint4*>(arow + kbase + 32), s, z, acc);
     }
 
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-    {
-        red[wave][0][lane][r] = acc0[r];
-        red[wave][1][lane][r] = acc1[r];
-    }
+        red[wave][lane][r] = acc[r];
     __syncthreads();
 
-    // 16 x 32 outputs, one per thread: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
-    const int om = tid >> 5, on = tid & 31;
-    const int t = on >> 4, src_lane = (om >> 2) * 16 + (on & 15), reg = om & 3;
+    // 16 x 16 outputs, one per thread: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int om = tid >> 4, on = tid & 15;
+    const int src_lane = (om >> 2) * 16 + on, reg = om & 3;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < GEMV_WAVES; ++w)
-        v += red[w][t][src_lane][reg];
+        v += red[w][src_lane][reg];
     if (m0 + om < a.m)
     {
-        const size_t oi = (size_t) (m0 + om) * a.n + n0 + on;
+        const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
         if (a.ksplit == 1)
         {
             if (a.bias)
-                v += T16<T>::to_float(a.bias[n0 + on]);
+                v += T16<T>::to_float(a.bias[nb * 16 + on]);
             a.out[oi] = T16<T>::from_float(v);
         }
         else
@@ -210,35 +303,57 @@ __global__ void woq_splitk_reduce_kernel(const float* slabs, const uint16_t* bia
     out[i] = T16<T>::from_float(v);
 }
 
+template <typename T, int WBITS, int ST>
+__device__ __forceinline__ void dequant_store_step(
+    const uint4& w, const WoqArgs& a, bool zero, int k0, int col, int lane)
+{
+    const size_t si = (size_t) (k0 / a.group) * a.n + col;
+    const float s = T16<T>::to_float(a.scales[si]);
+    const float z = zero ? T16<T>::to_float(a.zeros[si]) : 0.f;
+    const uint4 f = dequant_step<T, WBITS, ST>(w, s, z);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(&f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+    {
+        const int k = k0 + (lane >> 4) * 8 + j;
+        a.out[(size_t) k * a.n + col] = (uint16_t) (p[j >> 1] >> (16 * (j & 1)));
+    }
+}
+
 // Dense [k, n] dequantised weights from the GFX950 layout (test / tooling path; the reference's
 // tests recover them with an identity matmul, test_weight_only_quant_matmul.py:44-53).
+// grid: x = n-block, y = groups of 4 k-tiles (incl. the optional half tile); one wave per tile.
 template <typename T, int WBITS, bool ZERO>
 __global__ void woq_dequant_kernel(WoqArgs a)
 {
-    constexpr int KTILE = WBITS == 4 ? 64 : 32;
-    constexpr int KSTEPS = KTILE / 32;
+    constexpr int KTILE = Geo<WBITS>::KTILE;
     const int lane = threadIdx.x & 63;
     const int kt = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nb = blockIdx.x;
-    if (kt >= a.ktiles)
+    const bool half = WBITS == 4 && (a.k & 127) && kt == a.ktiles;
+    if (kt > a.ktiles || (kt == a.ktiles && !half))
         return;
-    const uint4 w = a.qweight[((size_t) nb * a.ktiles + kt) * 64 + lane];
-    uint4 frag[2][2];
-    dequant_tile<T, WBITS, ZERO>(w, a, kt, nb * 32, lane, frag);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+    const uint8_t* run = a.qweight + (size_t) nb * a.k * 16 * WBITS / 8;
+    uint4 w;
+    if (half)
+    {
+        const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) kt * 1024 + lane * 8);
+        w = make_uint4(hw.x, hw.y, 0, 0);
+    }
+    else
+        w = *reinterpret_cast<const uint4*>(run + (size_t) kt * 1024 + lane * 16);
+    const int col = nb * 16 + (lane & 15);
+    const int k0 = kt * KTILE;
+    dequant_store_step<T, WBITS, 0>(w, a, ZERO, k0, col, lane);
+    dequant_store_step<T, WBITS, 1>(w, a, ZERO, k0 + 32, col, lane);
+    if constexpr (WBITS == 4)
+    {
+        if (!half)
         {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(&frag[t][s]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-            {
-                const int k = kt * KTILE + s * 32 + (lane >> 4) * 8 + j;
-                const int n = nb * 32 + t * 16 + (lane & 15);
-                a.out[(size_t) k * a.n + n] = (uint16_t) (p[j >> 1] >> (16 * (j & 1)));
-            }
+            dequant_store_step<T, 4, 2>(w, a, ZERO, k0 + 64, col, lane);
+            dequant_store_step<T, 4, 3>(w, a, ZERO, k0 + 96, col, lane);
         }
+    }
 }
 
 template <typename T>
@@ -267,13 +382,13 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
     MQ_CHECK(p.weight_type == MI355Q_WEIGHT_INT4 || p.weight_type == MI355Q_WEIGHT_INT8, "weight_type %d", p.weight_type);
     MQ_CHECK(p.qweight && p.scales && p.out, "null tensor");
     MQ_CHECK(p.n > 0 && p.k > 0 && p.m >= 0, "bad m/n/k");
-    MQ_CHECK(p.k % 64 == 0 && p.n % 32 == 0, "k must be a multiple of 64 and n of 32 (k=%d n=%d)", p.k, p.n);
+    MQ_CHECK(p.k % 64 == 0 && p.n % 16 == 0, "k must be a multiple of 64 and n of 16 (k=%d n=%d)", p.k, p.n);
     const int group = p.group_size > 0 ? p.group_size : p.k;
     // fpA_intB_gemm_template.h:136-191: fine-grained => group size 64 or 128 (any multiple of 64 is
     // accepted here, like the SM90 path)
     MQ_CHECK(group % 64 == 0 && p.k % group == 0, "group_size %d must be a multiple of 64 dividing k=%d", group, p.k);
     WoqArgs a{};
-    a.qweight = reinterpret_cast<const uint4*>(p.qweight);
+    a.qweight = reinterpret_cast<const uint8_t*>(p.qweight);
     a.scales = reinterpret_cast<const uint16_t*>(p.scales);
     a.zeros = reinterpret_cast<const uint16_t*>(p.zeros);
     a.act = reinterpret_cast<const uint16_t*>(p.in);
@@ -283,7 +398,7 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
     a.n = p.n;
     a.k = p.k;
     a.group = group;
-    a.ktiles = p.k / (p.weight_type == MI355Q_WEIGHT_INT4 ? 64 : 32);
+    a.ktiles = p.k / (p.weight_type == MI355Q_WEIGHT_INT4 ? 128 : 64);
     a.ksplit = 1;
     return a;
 }
@@ -291,7 +406,7 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
 template <typename T, int WBITS, bool ZERO>
 void launch_gemv(const WoqArgs& a, hipStream_t stream)
 {
-    dim3 grid(a.n / 32, (a.m + 15) / 16, a.ksplit);
+    dim3 grid(a.n / 16, (a.m + 15) / 16, a.ksplit);
     hipLaunchKernelGGL((woq_gemv_kernel<T, WBITS, ZERO>), grid, dim3(GEMV_WAVES * 64), 0, stream, a);
     if (a.ksplit > 1)
     {
@@ -304,7 +419,7 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
 template <typename T, int WBITS, bool ZERO>
 void launch_dequant(const WoqArgs& a, hipStream_t stream)
 {
-    dim3 grid(a.n / 32, (a.ktiles + 3) / 4);
+    dim3 grid(a.n / 16, (a.ktiles + 1 + 3) / 4);
     hipLaunchKernelGGL((woq_dequant_kernel<T, WBITS, ZERO>), grid, dim3(256), 0, stream, a);
 }
 
@@ -325,15 +440,16 @@ void launch_dequant(const WoqArgs& a, hipStream_t stream)
 
 } // namespace
 
-// Split-K heuristic: fill >= 256 workgroups when the n-blocks alone cannot.
+// Split-K heuristic: only when the n-blocks alone leave most of the chip idle -- the reduce is a
+// second launch and costs more than a half-empty grid does.
 int woq_choose_ksplit(int m, int n, int k, int weight_type)
 {
-    const int ktiles = k / (weight_type == MI355Q_WEIGHT_INT4 ? 64 : 32);
-    const int wgs = (n / 32) * ((m + 15) / 16);
-    if (wgs >= 192)
+    const int ktiles = k / (weight_type == MI355Q_WEIGHT_INT4 ? 128 : 64);
+    const int wgs = (n / 16) * ((m + 15) / 16);
+    if (wgs >= 128)
         return 1;
     int s = (256 + wgs - 1) / wgs;
-    s = std::min(s, std::max(1, ktiles / (2 * GEMV_WAVES))); // keep >= 2 tiles per wave
+    s = std::min(s, std::max(1, ktiles / 16)); // keep >= 16 tiles per block
     return std::max(1, std::min(s, 16));
 }
 

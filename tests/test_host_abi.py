@@ -57,31 +57,34 @@ def test_reference_layout_batched_experts():
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("K", [128, 192, 64])
 @pytest.mark.parametrize("tq,bits", [(torch.int8, 8), (torch.quint4x2, 4)])
-def test_gfx950_layout_roundtrip_and_fragment_order(tq, bits):
-    K, N = 128, 64
+def test_gfx950_layout_roundtrip_and_fragment_order(tq, bits, K):
+    N = 64
     rng = np.random.default_rng(3)
     w = rng.integers(-128, 128, size=(K, N * bits // 8), dtype=np.int8)
     p = F.preprocess_weights_for_mixed_gemm(torch.from_numpy(w), tq, L.LAYOUT_GFX950)
     assert p.shape == (K, N * bits // 8)  # same tensor shape / byte count as the reference's layouts
     back = F.unprocess_weights_for_mixed_gemm(p, tq, L.LAYOUT_GFX950).numpy()
     assert (back == w).all()
-    # spot-check the documented map: lane l = h*16 + c of tile (nb, kt)
+    # spot-check the documented map: n-block of 16 columns, lane l = h*16 + c
     un = oracle.unpack_int4_packed_tensor_to_int8(w) if bits == 4 else w
     raw = p.numpy().view(np.uint8).ravel()
-    ktile = 64 if bits == 4 else 32
-    ktiles = K // ktile
-    for (k, n) in [(0, 0), (5, 17), (37, 40), (100, 63), (127, 31)]:
-        nb, t, c = n // 32, (n % 32) // 16, n % 16
+    ktile = 128 if bits == 4 else 64
+    run = K * 16 * bits // 8
+    for (k, n) in [(0, 0), (5, 17), (37, 40), (K - 28, 63), (63, 31), (K - 1, N - 1), (K - 64, 3)]:
+        nb, c = n // 16, n % 16
         kt, r = k // ktile, k % ktile
         s, h, j = r // 32, (r % 32) // 8, r % 8
-        byte = ((nb * ktiles + kt) * 64 + h * 16 + c) * 16
+        lane = h * 16 + c
         if bits == 4:
-            b = int(raw[byte + (t * 2 + s) * 4 + j // 2])
+            half = kt == K // 128
+            byte = nb * run + kt * 1024 + (lane * 8 if half else lane * 16) + s * 4
+            b = int(raw[byte + j // 2])
             v = (b >> 4) if j & 1 else (b & 0xF)
             v = v - 16 if v >= 8 else v
         else:
-            v = int(raw[byte + (t * 2 + j // 4) * 4 + j % 4])
+            v = int(raw[nb * run + kt * 1024 + lane * 16 + (s * 2 + j // 4) * 4 + j % 4])
             v = v - 256 if v >= 128 else v
         assert v == un[k, n]
 
