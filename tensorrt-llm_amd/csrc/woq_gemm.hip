@@ -31,7 +31,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int GEMV_WAVES = 4;
 constexpr int GEMV_CH = 4; // k-tiles per chunk
 
 struct WoqArgs
@@ -45,6 +44,7 @@ struct WoqArgs
     float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1
     int m, n, k;
     int group;  // group size in k; == k for per-channel
+    int group_shift; // log2(group); 31 for per-channel (k >> 31 == 0)
     int ktiles; // full k-tiles: k / KTILE
     int ksplit;
 };
@@ -115,45 +115,55 @@ __device__ __forceinline__ uint4 dequant_step(const uint4& w, float s, float z)
         return dequant8_int8<T>(wd[ST * 2], wd[ST * 2 + 1], s, z);
 }
 
-__device__ __forceinline__ uint4 load_nt(const uint4* p)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// SRD over `bytes` bytes at p (wave-uniform inputs only, so hipcc never wraps the loads in a
+// waterfall loop); out-of-range offsets return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes)
 {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (u >> 32));
+    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t) (bytes > 0xffffffffull ? 0xffffffffull : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void*) (((uint64_t) hi << 32) | lo), 0, nb, 0x00020000);
 }
 
-// Everything one wave needs for CH consecutive k-tiles of its n-block, issued as one burst of
-// independent, BRANCH-FREE loads (clamped addresses, so the compiler keeps the next chunk in flight
-// behind a counted vmcnt while this one is computed).  Weights: CH KiB contiguous per wave,
-// nontemporal (streamed once); activations and scales come from L2.
-template <int WBITS, int CH>
+// The weight side of CH consecutive k-tiles of one n-block, issued as one burst of independent,
+// branch-free buffer loads: per-lane byte offset in a VGPR (set once), the tile / group offset in an
+// SGPR -- no per-load vector address arithmetic.  Weights: CH KiB contiguous per wave, nontemporal
+// (streamed once); scales / zeros come from L2.
+// NSZ = (scale, zero) pairs per tile: 2 only for int4 with group size 64 (a 128-row tile spans two).
+template <int CH, int NSZ>
 struct GemvChunk
 {
     uint4 w[CH];
-    uint4 a[CH][Geo<WBITS>::KSTEPS];
-    uint16_t s[CH][Geo<WBITS>::NSZ], z[CH][Geo<WBITS>::NSZ];
+    uint16_t s[CH][NSZ], z[CH][NSZ];
 };
 
-template <typename T, int WBITS, bool ZERO, int CH>
-__device__ __forceinline__ void gemv_load_chunk(GemvChunk<WBITS, CH>& c, const WoqArgs& a, const uint4* wbase,
-    const uint16_t* arow, int kt0, int kt_last, int col)
+struct GemvSrc
+{
+    __amdgpu_buffer_rsrc_t w, s, z;
+    uint32_t w_voff, sz_voff; // lane * 16, col * 2
+    int group_shift;          // log2(group), or 31 for per-channel (every k maps to group 0)
+    uint32_t row_bytes;       // n * 2: stride between groups in scales / zeros
+};
+
+template <int WBITS, bool ZERO, int CH, int NSZ>
+__device__ __forceinline__ void gemv_load_chunk(GemvChunk<CH, NSZ>& c, const GemvSrc& src, int kt0, int kt_last)
 {
     constexpr int KTILE = Geo<WBITS>::KTILE;
 #pragma unroll
     for (int i = 0; i < CH; ++i)
     {
         const int kt = min(kt0 + i, kt_last); // tiles past the end re-read the last one; zeroed in compute
-        c.w[i] = load_nt(wbase + (size_t) kt * 64);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(src.w, src.w_voff, kt * 1024, 2 /* nt */);
+        c.w[i] = make_uint4(v.x, v.y, v.z, v.w);
 #pragma unroll
-        for (int st = 0; st < Geo<WBITS>::KSTEPS; ++st)
-            c.a[i][st] = *reinterpret_cast<const uint4*>(arow + (size_t) kt * KTILE + st * 32);
-#pragma unroll
-        for (int h = 0; h < Geo<WBITS>::NSZ; ++h)
+        for (int h = 0; h < NSZ; ++h)
         {
-            const int g = (kt * KTILE + h * 64) / a.group;
-            const size_t si = (size_t) g * a.n + col;
-            c.s[i][h] = a.scales[si];
-            c.z[i][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
+            const uint32_t goff = (uint32_t) ((kt * KTILE + h * 64) >> src.group_shift) * src.row_bytes;
+            c.s[i][h] = __builtin_amdgcn_raw_buffer_load_b16(src.s, src.sz_voff, goff, 0);
+            c.z[i][h] = ZERO ? __builtin_amdgcn_raw_buffer_load_b16(src.z, src.sz_voff, goff, 0) : (uint16_t) 0;
         }
     }
 }
@@ -164,43 +174,52 @@ __device__ __forceinline__ f32x4_t gemv_step(const uint4& w, const uint4& av, fl
     return mfma16<T>(av, dequant_step<T, WBITS, ST>(w, s, z), acc);
 }
 
-template <typename T, int WBITS, int CH>
-__device__ __forceinline__ void gemv_compute_chunk(const GemvChunk<WBITS, CH>& c, f32x4_t& acc, int kt0, int kt_end)
+// `afrag(kt, st)` returns the activation fragment of k-step st of tile kt (LDS or global).
+template <typename T, int WBITS, int CH, int NSZ, typename AF>
+__device__ __forceinline__ void gemv_compute_chunk(
+    const GemvChunk<CH, NSZ>& c, f32x4_t& acc, int kt0, int kt_end, int kt_last, AF afrag)
 {
 #pragma unroll
     for (int i = 0; i < CH; ++i)
     {
         const bool live = kt0 + i < kt_end; // wave-uniform; a dead tile gets scale = zero = 0 -> W = 0
+        const int kt = min(kt0 + i, kt_last);
         float s[2], z[2];
 #pragma unroll
-        for (int h = 0; h < Geo<WBITS>::NSZ; ++h)
+        for (int h = 0; h < NSZ; ++h)
         {
             s[h] = live ? T16<T>::to_float(c.s[i][h]) : 0.f;
             z[h] = live ? T16<T>::to_float(c.z[i][h]) : 0.f;
         }
         if constexpr (WBITS == 4)
         {
-            acc = gemv_step<T, 4, 0>(c.w[i], c.a[i][0], s[0], z[0], acc);
-            acc = gemv_step<T, 4, 1>(c.w[i], c.a[i][1], s[0], z[0], acc);
-            acc = gemv_step<T, 4, 2>(c.w[i], c.a[i][2], s[1], z[1], acc);
-            acc = gemv_step<T, 4, 3>(c.w[i], c.a[i][3], s[1], z[1], acc);
+            constexpr int H1 = NSZ - 1;
+            acc = gemv_step<T, 4, 0>(c.w[i], afrag(kt, 0), s[0], z[0], acc);
+            acc = gemv_step<T, 4, 1>(c.w[i], afrag(kt, 1), s[0], z[0], acc);
+            acc = gemv_step<T, 4, 2>(c.w[i], afrag(kt, 2), s[H1], z[H1], acc);
+            acc = gemv_step<T, 4, 3>(c.w[i], afrag(kt, 3), s[H1], z[H1], acc);
         }
         else
         {
-            acc = gemv_step<T, 8, 0>(c.w[i], c.a[i][0], s[0], z[0], acc);
-            acc = gemv_step<T, 8, 1>(c.w[i], c.a[i][1], s[0], z[0], acc);
+            acc = gemv_step<T, 8, 0>(c.w[i], afrag(kt, 0), s[0], z[0], acc);
+            acc = gemv_step<T, 8, 1>(c.w[i], afrag(kt, 1), s[0], z[0], acc);
         }
     }
 }
 
-// grid: x = n-block (16 columns), y = 16-row chunk of m, z = k split.  block = 4 waves; wave w owns
-// the chunks w, w+4, ... (CH k-tiles each) of the block's k range (ping-pong register sets).
-template <typename T, int WBITS, bool ZERO>
-__global__ __launch_bounds__(GEMV_WAVES * 64) void woq_gemv_kernel(WoqArgs a)
+// grid: x = n-block (16 columns), y = 16-row chunk of m, z = k split.  block = NWAVES waves; wave w
+// owns the chunks w, w+NWAVES, ... (CH k-tiles each) of the block's k range (ping-pong register
+// sets).  LDS_A: the block's activation rows [rows][k range] are staged once into LDS (row stride
+// k*2+32 bytes: conflict-free ds_read_b128 fragments) so the per-tile activation traffic leaves
+// the vector-memory path, which is then used by the weight stream alone.
+template <typename T, int WBITS, bool ZERO, int NWAVES, bool LDS_A, int NSZ>
+__global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
     constexpr int CH = GEMV_CH;
     constexpr int KTILE = Geo<WBITS>::KTILE;
-    __shared__ float red[GEMV_WAVES][64][4];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // red[NWAVES][64][4] floats, then A rows
+    float* red = reinterpret_cast<float*>(smem);
+    uint8_t* a_lds = smem + NWAVES * 64 * 4 * sizeof(float);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -209,40 +228,76 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void woq_gemv_kernel(WoqArgs a)
     const int m0 = blockIdx.y * 16;
     const int col = nb * 16 + (lane & 15);
     const int kh = (lane >> 4) * 8;
+    const int rows = min(16, a.m - m0);
 
     const int per = (a.ktiles + a.ksplit - 1) / a.ksplit;
     const int kt_begin = blockIdx.z * per;
     const int kt_end = min(a.ktiles, kt_begin + per);
     const int kt_last = max(kt_end - 1, 0);
+    const bool half_tile = WBITS == 4 && (a.k & 127) && blockIdx.z == a.ksplit - 1;
+    // k range [k_lo, k_hi) this block touches (incl. the half tile)
+    const int k_lo = kt_begin * KTILE;
+    const int k_hi = half_tile ? a.k : kt_end * KTILE;
 
     const size_t run_bytes = (size_t) a.k * 16 * WBITS / 8;
     const uint8_t* run = a.qweight + (size_t) nb * run_bytes;
-    const uint4* wbase = reinterpret_cast<const uint4*>(run) + lane;
-    // rows >= m are clamped to row m-1: their MFMA output rows are computed but never stored
-    const uint16_t* arow = a.act + (size_t) min(m0 + (lane & 15), a.m - 1) * a.k + kh;
+    GemvSrc src;
+    src.w = make_rsrc(run, run_bytes);
+    const size_t sz_bytes = (size_t) (a.k / a.group) * a.n * 2;
+    src.s = make_rsrc(a.scales, sz_bytes);
+    src.z = make_rsrc(ZERO ? a.zeros : a.scales, sz_bytes);
+    src.w_voff = lane * 16;
+    src.sz_voff = col * 2;
+    src.group_shift = a.group_shift;
+    src.row_bytes = a.n * 2;
+    // rows >= m are clamped to the last valid row: their MFMA output rows are computed, never stored
+    const int rloc = min(lane & 15, rows - 1);
+    const uint16_t* arow = a.act + (size_t) (m0 + rloc) * a.k + kh;
+    const int lds_stride = (k_hi - k_lo) * 2 + 32;
+
+    constexpr int STRIDE = NWAVES * CH;
+    GemvChunk<CH, NSZ> ca, cb;
+    int kt0 = kt_begin + wave * CH;
+    if (kt0 < kt_end) // weights first: their HBM latency overlaps the activation staging below
+        gemv_load_chunk<WBITS, ZERO, CH, NSZ>(ca, src, kt0, kt_last);
+
+    if constexpr (LDS_A)
+    {
+        const int vec_per_row = (k_hi - k_lo) / 8; // 16-byte vectors
+        for (int i = tid; i < rows * vec_per_row; i += NWAVES * 64)
+        {
+            const int r = i / vec_per_row, v = i % vec_per_row;
+            *reinterpret_cast<uint4*>(a_lds + r * lds_stride + v * 16)
+                = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
+        }
+        __syncthreads();
+    }
+    const uint8_t* a_lane = a_lds + rloc * lds_stride + (kh - k_lo) * 2;
+    auto afrag = [&](int kt, int st) -> uint4
+    {
+        if constexpr (LDS_A)
+            return *reinterpret_cast<const uint4*>(a_lane + (kt * KTILE + st * 32) * 2);
+        else
+            return *reinterpret_cast<const uint4*>(arow + (size_t) kt * KTILE + st * 32);
+    };
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-
-    constexpr int STRIDE = GEMV_WAVES * CH;
-    GemvChunk<WBITS, CH> ca, cb;
-    int kt0 = kt_begin + wave * CH;
     if (kt0 < kt_end)
     {
-        gemv_load_chunk<T, WBITS, ZERO, CH>(ca, a, wbase, arow, kt0, kt_last, col);
         while (true)
         {
             // invariant: `ca` holds chunk kt0
             const bool more_b = kt0 + STRIDE < kt_end;
             if (more_b)
-                gemv_load_chunk<T, WBITS, ZERO, CH>(cb, a, wbase, arow, kt0 + STRIDE, kt_last, col);
-            gemv_compute_chunk<T, WBITS, CH>(ca, acc, kt0, kt_end);
+                gemv_load_chunk<WBITS, ZERO, CH, NSZ>(cb, src, kt0 + STRIDE, kt_last);
+            gemv_compute_chunk<T, WBITS, CH, NSZ>(ca, acc, kt0, kt_end, kt_last, afrag);
             if (!more_b)
                 break;
             kt0 += STRIDE;
             const bool more_a = kt0 + STRIDE < kt_end;
             if (more_a)
-                gemv_load_chunk<T, WBITS, ZERO, CH>(ca, a, wbase, arow, kt0 + STRIDE, kt_last, col);
-            gemv_compute_chunk<T, WBITS, CH>(cb, acc, kt0, kt_end);
+                gemv_load_chunk<WBITS, ZERO, CH, NSZ>(ca, src, kt0 + STRIDE, kt_last);
+            gemv_compute_chunk<T, WBITS, CH, NSZ>(cb, acc, kt0, kt_end, kt_last, afrag);
             if (!more_a)
                 break;
             kt0 += STRIDE;
@@ -251,41 +306,44 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void woq_gemv_kernel(WoqArgs a)
 
     // int4 with K % 128 == 64: the run ends with a 512-byte half tile (2 k-steps); wave 0 of the
     // last k split takes it
-    if (WBITS == 4 && (a.k & 127) && blockIdx.z == a.ksplit - 1 && wave == 0)
+    if (half_tile && wave == 0)
     {
         const int kbase = a.ktiles * KTILE;
         const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) a.ktiles * 1024 + lane * 8);
-        const size_t si = (size_t) (kbase / a.group) * a.n + col;
+        const size_t si = (size_t) (kbase >> a.group_shift) * a.n + col;
         const float s = T16<T>::to_float(a.scales[si]);
         const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
         const uint4 w = make_uint4(hw.x, hw.y, 0, 0);
-        acc = gemv_step<T, 4, 0>(w, *reinterpret_cast<const uint4*>(arow + kbase), s, z, acc);
-        acc = gemv_step<T, 4, 1>(w, *reinterpret_cast<const uint4*>(arow + kbase + 32), s, z, acc);
+        acc = gemv_step<T, 4, 0>(w, afrag(a.ktiles, 0), s, z, acc);
+        acc = gemv_step<T, 4, 1>(w, afrag(a.ktiles, 1), s, z, acc);
     }
 
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        red[wave][lane][r] = acc[r];
+        red[(wave * 64 + lane) * 4 + r] = acc[r];
     __syncthreads();
 
-    // 16 x 16 outputs, one per thread: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
-    const int om = tid >> 4, on = tid & 15;
-    const int src_lane = (om >> 2) * 16 + on, reg = om & 3;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < GEMV_WAVES; ++w)
-        v += red[w][src_lane][reg];
-    if (m0 + om < a.m)
+    // 16 x 16 outputs: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (tid < 256)
     {
-        const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
-        if (a.ksplit == 1)
+        const int om = tid >> 4, on = tid & 15;
+        const int src_lane = (om >> 2) * 16 + on, reg = om & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w)
+            v += red[(w * 64 + src_lane) * 4 + reg];
+        if (om < rows)
         {
-            if (a.bias)
-                v += T16<T>::to_float(a.bias[nb * 16 + on]);
-            a.out[oi] = T16<T>::from_float(v);
+            const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
+            if (a.ksplit == 1)
+            {
+                if (a.bias)
+                    v += T16<T>::to_float(a.bias[nb * 16 + on]);
+                a.out[oi] = T16<T>::from_float(v);
+            }
+            else
+                a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = v;
         }
-        else
-            a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = v;
     }
 }
 
@@ -307,7 +365,7 @@ template <typename T, int WBITS, int ST>
 __device__ __forceinline__ void dequant_store_step(
     const uint4& w, const WoqArgs& a, bool zero, int k0, int col, int lane)
 {
-    const size_t si = (size_t) (k0 / a.group) * a.n + col;
+    const size_t si = (size_t) (k0 >> a.group_shift) * a.n + col;
     const float s = T16<T>::to_float(a.scales[si]);
     const float z = zero ? T16<T>::to_float(a.zeros[si]) : 0.f;
     const uint4 f = dequant_step<T, WBITS, ST>(w, s, z);
@@ -398,16 +456,58 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
     a.n = p.n;
     a.k = p.k;
     a.group = group;
+    if (p.group_size > 0)
+    {
+        MQ_CHECK((group & (group - 1)) == 0, "group_size %d must be a power of two", group);
+        a.group_shift = 0;
+        while ((1 << a.group_shift) < group)
+            ++a.group_shift;
+    }
+    else
+        a.group_shift = 31;
     a.ktiles = p.k / (p.weight_type == MI355Q_WEIGHT_INT4 ? 128 : 64);
     a.ksplit = 1;
     return a;
+}
+
+template <typename T, int WBITS, bool ZERO, int NWAVES, bool LDS_A>
+void launch_gemv_variant(const WoqArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    // two (scale, zero) pairs per tile only when a 128-row int4 tile spans two groups of 64
+    const bool split = WBITS == 4 && a.group == 64;
+    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, LDS_A, (WBITS == 4 ? 2 : 1)>
+                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, LDS_A, 1>;
+    if (lds_bytes > 64 * 1024)
+    {
+        MQ_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), lds_bytes, stream, a);
 }
 
 template <typename T, int WBITS, bool ZERO>
 void launch_gemv(const WoqArgs& a, hipStream_t stream)
 {
     dim3 grid(a.n / 16, (a.m + 15) / 16, a.ksplit);
-    hipLaunchKernelGGL((woq_gemv_kernel<T, WBITS, ZERO>), grid, dim3(GEMV_WAVES * 64), 0, stream, a);
+    constexpr int KTILE = Geo<WBITS>::KTILE;
+    const int per = (a.ktiles + a.ksplit - 1) / a.ksplit;
+    const int krange = per * KTILE + (WBITS == 4 ? (a.k & 127) : 0);
+    const size_t red_bytes = 8 * 64 * 4 * sizeof(float);
+    const size_t a_bytes = (size_t) std::min(16, a.m) * (krange * 2 + 32);
+    // activation rows in LDS when they fit beside a second resident block (<= 72 KiB), or, for a
+    // taller slab, when one block per CU is all the grid asks for anyway
+    const bool lds_a = red_bytes + a_bytes <= 72 * 1024
+        || (red_bytes + a_bytes <= 150 * 1024 && grid.x * grid.y * grid.z <= 320);
+    // 8 waves when a block owns enough tiles to keep them all busy
+    const bool w8 = per >= 32;
+    if (lds_a && w8)
+        launch_gemv_variant<T, WBITS, ZERO, 8, true>(a, grid, red_bytes + a_bytes, stream);
+    else if (lds_a)
+        launch_gemv_variant<T, WBITS, ZERO, 4, true>(a, grid, red_bytes + a_bytes, stream);
+    else if (w8)
+        launch_gemv_variant<T, WBITS, ZERO, 8, false>(a, grid, red_bytes, stream);
+    else
+        launch_gemv_variant<T, WBITS, ZERO, 4, false>(a, grid, red_bytes, stream);
     if (a.ksplit > 1)
     {
         const size_t total = (size_t) a.m * a.n;

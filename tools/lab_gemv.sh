@@ -1,8 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/lab
-for dbg in 0 1 2 4 5 6 7; do
-for shape in "1 4096 4096" "1 28672 8192"; do
+timeout -k 10 300 python -u -m pytest tests/test_gpu_gemm.py -m gpu -x -q --timeout 120 --timeout-method thread -k "weight_only or groupwise or ingested" 2>&1 | tail -3 || exit 1
+for shape in "1 4096 4096" "4 4096 4096" "16 4096 4096" "1 11008 4096" "1 4096 11008" "1 12288 4096" "1 28672 8192" "1 8192 8192" "16 28672 8192"; do
   set -- $shape
-  MI355Q_DBG=$dbg timeout -k 10 120 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lab/g -- python3 tools/microbench.py gemv --m $1 --n $2 --k $3 > gpurun_out/lab/out.txt 2>/dev/null
-  echo "dbg=$dbg m=$1 n=$2 k=$3 rocprof(avg,min,max)=$(python3 tools/summarize_rocprof.py $(ls -t $(find gpurun_out/lab/g -name '*kernel_trace.csv') | head -1) woq_gemv | tail -1 | awk '{print $(NF-2), $(NF-1), $NF}')"
-done
+  timeout -k 10 120 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lab/g -- python3 tools/microbench.py gemv --m $1 --n $2 --k $3 > gpurun_out/lab/out.txt 2>/dev/null
+  echo "m=$1 n=$2 k=$3 MB=$(python3 -c "import json;print(round(json.load(open('gpurun_out/lab/out.txt'))['algorithmic_bytes']/1e6,1))") rocprof(avg,min,max)=$(python3 tools/summarize_rocprof.py $(ls -t $(find gpurun_out/lab/g -name '*kernel_trace.csv') | head -1) woq_gemv | tail -1 | awk '{print $(NF-2), $(NF-1), $NF}')"
 done
