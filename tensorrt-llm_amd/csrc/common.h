@@ -125,6 +125,7 @@ struct T16;
 template <>
 struct T16<bf16_t>
 {
+    static constexpr bool is_bf16 = true;
     static __device__ __forceinline__ float to_float(uint32_t b)
     {
         return bf16_bits_to_float(b);
@@ -146,6 +147,7 @@ struct T16<bf16_t>
 template <>
 struct T16<f16_t>
 {
+    static constexpr bool is_bf16 = false;
     static __device__ __forceinline__ float to_float(uint32_t b)
     {
         return f16_bits_to_float(b);

@@ -82,12 +82,14 @@ struct Sm80Map
 // ---- GFX950: MFMA-fragment-major tiles.
 //   n-block = 16 columns; the k-tiles of an n-block are contiguous ("tile run").
 //   int4: k-tile = 128 rows = 1 KiB = 64 lanes x 16 B.  Lane l = h*16 + c owns column c and, in
-//         dword s (k-step s of 32 rows), the 8 consecutive rows k = 8h .. 8h+7 as nibbles 0..7 --
-//         exactly the B operand fragment of v_mfma_f32_16x16x32_{bf16,f16}: one
-//         global_load_dwordx4 per lane feeds 4 MFMAs with no shuffle.  When K % 128 == 64 the run
+//         dword s (k-step s of 32 rows), the 8 consecutive rows k = 8h .. 8h+7 -- the B operand
+//         fragment of v_mfma_f32_16x16x32_{bf16,f16}: one 16-byte load per lane feeds 4 MFMAs with
+//         no shuffle.  Row 8h+j sits at nibble j < 4 ? 2j : 2(j-4)+1 and is stored biased (q + 8),
+//         so `w & 0x0f0f0f0f` / `(w >> 4) & 0x0f0f0f0f` are rows 0..3 / 4..7 as bytes 0..15, which
+//         v_cvt_scalef32_pk_{bf16,f16}_fp8 turns into 16-bit floats two at a time (woq_gemm.hip).  When K % 128 == 64 the run
 //         ends with a 512-byte half tile (64 rows: lane l owns 8 B at l*8, dwords s = 0, 1).
 //   int8: k-tile = 64 rows = 1 KiB.  Lane l owns dwords (s*2 + j/4), byte j%4 for k-step s = 0, 1.
-//   Values stay signed two's complement (no bias); byte count == the row-major tensor's.
+//   int8 values stay signed two's complement; byte count == the row-major tensor's.
 struct Gfx950Map
 {
     int bits;
@@ -110,7 +112,7 @@ struct Gfx950Map
             const size_t lane = h * 16 + c;
             const bool half = kt == K / 128; // trailing 64-row half tile
             const size_t byte = base + kt * 1024 + (half ? lane * 8 : lane * 16) + s * 4;
-            return byte * 2 + j;
+            return byte * 2 + (j < 4 ? 2 * j : 2 * (j - 4) + 1);
         }
         const size_t kt = k / 64, r = k % 64;
         const size_t s = r / 32, h = (r % 32) / 8, j = r % 8;
@@ -156,7 +158,8 @@ void transform(int8_t* dst8, const int8_t* src8, const size_t shape[3], int weig
     const size_t mat_bytes = K * N * bits / 8;
     const Geometry g{K, N, bits};
     const int mask = bits == 8 ? 0xff : 0xf;
-    const int bias = layout == MI355Q_LAYOUT_REF_SM80 ? (bits == 8 ? 128 : 8) : 0; // signed -> unsigned, :386-432
+    // signed -> unsigned: SM80 both widths (:386-432); GFX950 int4 only (u = q + 8 feeds the fp8-style unpack)
+    const int bias = layout == MI355Q_LAYOUT_REF_SM80 ? (bits == 8 ? 128 : 8) : (layout == MI355Q_LAYOUT_GFX950 && bits == 4 ? 8 : 0);
     const Sm80Map sm80(g);
     const Gfx950Map gfx(g);
     std::vector<uint8_t> tmp(mat_bytes);

@@ -31,7 +31,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int GEMV_CH = 4; // k-tiles per chunk
 
 struct WoqArgs
 {
@@ -69,19 +68,64 @@ __device__ __forceinline__ float sbyte(uint32_t w, int i)
     return (float) (int8_t) (w >> (8 * i)); // v_cvt_f32_i32_sdwa sext(BYTE_i)
 }
 
-// 8 signed int4 (one dword, nibble j = element j) -> 8 dequantised 16-bit values (4 packed dwords).
-// lo/hi bytes carry 16*q exactly, so the fma uses scale/16 (a power-of-two rescale: exact).
+// GFX950 int4 dword (preprocess.cpp Gfx950Map): element j of the lane's 8-row fragment is stored
+// biased (u = q + 8) at nibble j < 4 ? 2j : 2(j-4)+1, i.e. `w & 0x0f0f0f0f` holds elements 0..3 as
+// bytes and `(w >> 4) & 0x0f0f0f0f` elements 4..7.
+//
+// Exact dequantisation: 8 int4 -> 8 values round16(fma(q, scale, zero)) (4 packed dwords).
+// After the xor the nibbles are two's complement again; lo/hi bytes carry 16*q exactly, so the fma
+// uses scale/16 (a power-of-two rescale: exact).
 template <typename T>
 __device__ __forceinline__ uint4 dequant8_int4(uint32_t w, float s16, float z)
 {
-    const uint32_t lo = (w << 4) & 0xf0f0f0f0u; // byte i = 16 * q[2i]
-    const uint32_t hi = w & 0xf0f0f0f0u;        // byte i = 16 * q[2i+1]
+    w ^= 0x88888888u;
+    const uint32_t lo = (w << 4) & 0xf0f0f0f0u; // byte i = 16 * q[i]
+    const uint32_t hi = w & 0xf0f0f0f0u;        // byte i = 16 * q[4+i]
     uint4 r;
-    r.x = pack2<T>(fmaf(sbyte(lo, 0), s16, z), fmaf(sbyte(hi, 0), s16, z));
-    r.y = pack2<T>(fmaf(sbyte(lo, 1), s16, z), fmaf(sbyte(hi, 1), s16, z));
-    r.z = pack2<T>(fmaf(sbyte(lo, 2), s16, z), fmaf(sbyte(hi, 2), s16, z));
-    r.w = pack2<T>(fmaf(sbyte(lo, 3), s16, z), fmaf(sbyte(hi, 3), s16, z));
+    r.x = pack2<T>(fmaf(sbyte(lo, 0), s16, z), fmaf(sbyte(lo, 1), s16, z));
+    r.y = pack2<T>(fmaf(sbyte(lo, 2), s16, z), fmaf(sbyte(lo, 3), s16, z));
+    r.z = pack2<T>(fmaf(sbyte(hi, 0), s16, z), fmaf(sbyte(hi, 1), s16, z));
+    r.w = pack2<T>(fmaf(sbyte(hi, 2), s16, z), fmaf(sbyte(hi, 3), s16, z));
     return r;
+}
+
+// Integer-domain unpack for the decode GEMV: 8 biased int4 -> the 8 integers u = 0..15 as exact
+// 16-bit floats.  A byte 0x00..0x0f read as OCP e4m3 is u * 2^-9 (denormals 0..7, then exponent 1),
+// so v_cvt_scalef32_pk_{bf16,f16}_fp8 with scale 2^9 converts two nibbles per instruction:
+// 3 mask/shift + 4 convert VALU ops per 8 weights instead of 23 for the exact dequantisation.
+template <typename T>
+__device__ __forceinline__ uint32_t cvt2_u4(uint32_t bytes, bool hi_word);
+template <>
+__device__ __forceinline__ uint32_t cvt2_u4<bf16_t>(uint32_t bytes, bool hi_word)
+{
+    return hi_word ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(bytes, 512.f, true))
+                   : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(bytes, 512.f, false));
+}
+template <>
+__device__ __forceinline__ uint32_t cvt2_u4<f16_t>(uint32_t bytes, bool hi_word)
+{
+    return hi_word ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(bytes, 512.f, true))
+                   : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(bytes, 512.f, false));
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 unpack8_u4(uint32_t w)
+{
+    const uint32_t lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
+    uint4 r;
+    r.x = cvt2_u4<T>(lo, false);
+    r.y = cvt2_u4<T>(lo, true);
+    r.z = cvt2_u4<T>(hi, false);
+    r.w = cvt2_u4<T>(hi, true);
+    return r;
+}
+
+// sixteen 1.0s: the B operand that turns an MFMA into the row sums of A
+template <typename T>
+__device__ __forceinline__ uint4 ones8()
+{
+    constexpr uint32_t one2 = T16<T>::is_bf16 ? 0x3f803f80u : 0x3c003c00u;
+    return make_uint4(one2, one2, one2, one2);
 }
 
 // 8 signed int8 (two dwords) -> 8 dequantised 16-bit values
@@ -174,6 +218,38 @@ __device__ __forceinline__ f32x4_t gemv_step(const uint4& w, const uint4& av, fl
     return mfma16<T>(av, dequant_step<T, WBITS, ST>(w, s, z), acc);
 }
 
+// One int4 k-tile (STEPS k-steps of 32 rows) in the integer domain.  Per scale group g of the tile:
+//     P  = sum_k a[m,k] * u[k,n]      (MFMA, u = q + 8 exact in 16 bits, fp32 accumulate)
+//     S1 = sum_k a[m,k]               (MFMA against ones)
+//     acc += scale * P + (zero - 8 * scale) * S1   ==   sum_k a * (q * scale + zero)
+// i.e. the scale / zero are applied to the group's partial sums (8-9 VALU ops per group) instead of
+// to every weight.  Unlike kernel.h:364-365 / mma_tensorop_dequantizer.h the dequantised weight is
+// not rounded to 16 bits before the multiply, so results differ from the exact-dequant path by
+// about half an output ulp (closer to the real-number result); mi355q_weight_only_dequantize and
+// the prefill GEMM keep the bit-exact rounding.
+template <typename T, int NSZ, int STEPS, typename AF>
+__device__ __forceinline__ void gemv_tile_int4(const uint4& w, f32x4_t& acc, const float* s, const float* z, AF afrag)
+{
+    const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w);
+    constexpr int PER = STEPS / NSZ; // k-steps per scale group
+#pragma unroll
+    for (int h = 0; h < NSZ; ++h)
+    {
+        f32x4_t P = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = h * PER; st < (h + 1) * PER; ++st)
+        {
+            const uint4 av = afrag(st);
+            P = mfma16<T>(av, unpack8_u4<T>(wd[st]), P);
+            S1 = mfma16<T>(av, ones8<T>(), S1);
+        }
+        const float zc = fmaf(-8.f, s[h], z[h]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[r] = fmaf(zc, S1[r], fmaf(s[h], P[r], acc[r]));
+    }
+}
+
 // `afrag(kt, st)` returns the activation fragment of k-step st of tile kt (LDS or global).
 template <typename T, int WBITS, int CH, int NSZ, typename AF>
 __device__ __forceinline__ void gemv_compute_chunk(
@@ -192,13 +268,7 @@ __device__ __forceinline__ void gemv_compute_chunk(
             z[h] = live ? T16<T>::to_float(c.z[i][h]) : 0.f;
         }
         if constexpr (WBITS == 4)
-        {
-            constexpr int H1 = NSZ - 1;
-            acc = gemv_step<T, 4, 0>(c.w[i], afrag(kt, 0), s[0], z[0], acc);
-            acc = gemv_step<T, 4, 1>(c.w[i], afrag(kt, 1), s[0], z[0], acc);
-            acc = gemv_step<T, 4, 2>(c.w[i], afrag(kt, 2), s[H1], z[H1], acc);
-            acc = gemv_step<T, 4, 3>(c.w[i], afrag(kt, 3), s[H1], z[H1], acc);
-        }
+            gemv_tile_int4<T, NSZ, 4>(c.w[i], acc, s, z, [&](int st) { return afrag(kt, st); });
         else
         {
             acc = gemv_step<T, 8, 0>(c.w[i], afrag(kt, 0), s[0], z[0], acc);
@@ -207,15 +277,16 @@ __device__ __forceinline__ void gemv_compute_chunk(
     }
 }
 
-// grid: x = n-block (16 columns), y = 16-row chunk of m, z = k split.  block = NWAVES waves; wave w
-// owns the chunks w, w+NWAVES, ... (CH k-tiles each) of the block's k range (ping-pong register
-// sets).  LDS_A: the block's activation rows [rows][k range] are staged once into LDS (row stride
-// k*2+32 bytes: conflict-free ds_read_b128 fragments) so the per-tile activation traffic leaves
-// the vector-memory path, which is then used by the weight stream alone.
-template <typename T, int WBITS, bool ZERO, int NWAVES, bool LDS_A, int NSZ>
+// Persistent decode kernel.  grid: x = n-group, y = 16-row chunk of m, z = k segment; block =
+// NWAVES waves.  A block stages its activation rows [rows][k segment] into LDS once (row stride
+// kseg*2+32 bytes: conflict-free ds_read_b128 fragments) and then walks the n-blocks x, x+gridDim.x,
+// ...: wave w owns a contiguous range of the segment's k-tiles, cut into chunks of CH tiles, and
+// runs ONE ping-pong load pipeline over the whole (n-block, chunk) sequence, so the next n-block's
+// weights are already in flight while the current one is reduced (LDS, one 16x16 tile per n-block)
+// and stored -- the HBM queue never drains between n-blocks.
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ>
 __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
-    constexpr int CH = GEMV_CH;
     constexpr int KTILE = Geo<WBITS>::KTILE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // red[NWAVES][64][4] floats, then A rows
     float* red = reinterpret_cast<float*>(smem);
@@ -224,125 +295,144 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = blockIdx.x;
     const int m0 = blockIdx.y * 16;
-    const int col = nb * 16 + (lane & 15);
     const int kh = (lane >> 4) * 8;
     const int rows = min(16, a.m - m0);
+    const int nblocks = a.n >> 4;
+    const int nb_stride = gridDim.x;
 
-    const int per = (a.ktiles + a.ksplit - 1) / a.ksplit;
-    const int kt_begin = blockIdx.z * per;
-    const int kt_end = min(a.ktiles, kt_begin + per);
-    const int kt_last = max(kt_end - 1, 0);
+    // k segment of this block, and this wave's contiguous tile range in it
+    const int seg = (a.ktiles + a.ksplit - 1) / a.ksplit; // 0 when k == 64 on int4: half tile only
+    const int seg_begin = blockIdx.z * seg;
+    const int seg_end = min(a.ktiles, seg_begin + seg);
+    const int tpw = (seg + NWAVES - 1) / NWAVES; // tiles per wave (block-uniform)
+    const int cpw = max(1, (tpw + CH - 1) / CH);   // chunks per wave per n-block (block-uniform)
+    const int kt_begin = seg_begin + wave * tpw;
+    const int kt_end = min(seg_end, kt_begin + tpw); // may be <= kt_begin: this wave only helps reduce
+    const int kt_hi = max(seg_end - 1, 0);           // clamp for dead tiles (a valid tile of the segment)
     const bool half_tile = WBITS == 4 && (a.k & 127) && blockIdx.z == a.ksplit - 1;
-    // k range [k_lo, k_hi) this block touches (incl. the half tile)
-    const int k_lo = kt_begin * KTILE;
-    const int k_hi = half_tile ? a.k : kt_end * KTILE;
+    const int k_lo = seg_begin * KTILE;
+    const int k_hi = half_tile ? a.k : seg_end * KTILE;
 
     const size_t run_bytes = (size_t) a.k * 16 * WBITS / 8;
-    const uint8_t* run = a.qweight + (size_t) nb * run_bytes;
-    GemvSrc src;
-    src.w = make_rsrc(run, run_bytes);
     const size_t sz_bytes = (size_t) (a.k / a.group) * a.n * 2;
+    GemvSrc src;
     src.s = make_rsrc(a.scales, sz_bytes);
     src.z = make_rsrc(ZERO ? a.zeros : a.scales, sz_bytes);
     src.w_voff = lane * 16;
-    src.sz_voff = col * 2;
     src.group_shift = a.group_shift;
     src.row_bytes = a.n * 2;
+    auto issue = [&](GemvChunk<CH, NSZ>& c, int nb, int ck)
+    {
+        src.w = make_rsrc(a.qweight + (size_t) nb * run_bytes, run_bytes);
+        src.sz_voff = (nb * 16 + (lane & 15)) * 2;
+        gemv_load_chunk<WBITS, ZERO, CH, NSZ>(c, src, kt_begin + ck * CH, kt_hi);
+    };
+
     // rows >= m are clamped to the last valid row: their MFMA output rows are computed, never stored
     const int rloc = min(lane & 15, rows - 1);
-    const uint16_t* arow = a.act + (size_t) (m0 + rloc) * a.k + kh;
     const int lds_stride = (k_hi - k_lo) * 2 + 32;
 
-    constexpr int STRIDE = NWAVES * CH;
     GemvChunk<CH, NSZ> ca, cb;
-    int kt0 = kt_begin + wave * CH;
-    if (kt0 < kt_end) // weights first: their HBM latency overlaps the activation staging below
-        gemv_load_chunk<WBITS, ZERO, CH, NSZ>(ca, src, kt0, kt_last);
+    int l_nb = blockIdx.x, l_ck = 0; // next chunk to load
+    auto load_next = [&](GemvChunk<CH, NSZ>& c)
+    {
+        if (l_nb < nblocks)
+        {
+            issue(c, l_nb, l_ck);
+            if (++l_ck == cpw)
+            {
+                l_ck = 0;
+                l_nb += nb_stride;
+            }
+        }
+    };
+    load_next(ca); // weights first: their HBM latency overlaps the activation staging below
 
-    if constexpr (LDS_A)
     {
         const int vec_per_row = (k_hi - k_lo) / 8; // 16-byte vectors
         for (int i = tid; i < rows * vec_per_row; i += NWAVES * 64)
         {
-            const int r = i / vec_per_row, v = i % vec_per_row;
+            const int r = i / vec_per_row, v = i - r * vec_per_row;
             *reinterpret_cast<uint4*>(a_lds + r * lds_stride + v * 16)
                 = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
         }
-        __syncthreads();
     }
+    __syncthreads();
     const uint8_t* a_lane = a_lds + rloc * lds_stride + (kh - k_lo) * 2;
     auto afrag = [&](int kt, int st) -> uint4
-    {
-        if constexpr (LDS_A)
-            return *reinterpret_cast<const uint4*>(a_lane + (kt * KTILE + st * 32) * 2);
-        else
-            return *reinterpret_cast<const uint4*>(arow + (size_t) kt * KTILE + st * 32);
-    };
+    { return *reinterpret_cast<const uint4*>(a_lane + (kt * KTILE + st * 32) * 2); };
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    if (kt0 < kt_end)
+
+    // end of an n-block: (half tile,) cross-wave reduce, bias, store
+    auto flush = [&](int nb)
     {
-        while (true)
+        if (half_tile && wave == 0)
         {
-            // invariant: `ca` holds chunk kt0
-            const bool more_b = kt0 + STRIDE < kt_end;
-            if (more_b)
-                gemv_load_chunk<WBITS, ZERO, CH, NSZ>(cb, src, kt0 + STRIDE, kt_last);
-            gemv_compute_chunk<T, WBITS, CH, NSZ>(ca, acc, kt0, kt_end, kt_last, afrag);
-            if (!more_b)
-                break;
-            kt0 += STRIDE;
-            const bool more_a = kt0 + STRIDE < kt_end;
-            if (more_a)
-                gemv_load_chunk<WBITS, ZERO, CH, NSZ>(ca, src, kt0 + STRIDE, kt_last);
-            gemv_compute_chunk<T, WBITS, CH, NSZ>(cb, acc, kt0, kt_end, kt_last, afrag);
-            if (!more_a)
-                break;
-            kt0 += STRIDE;
+            // int4 with K % 128 == 64: the run ends with a 512-byte half tile (2 k-steps)
+            const int col = nb * 16 + (lane & 15);
+            const uint8_t* run = a.qweight + (size_t) nb * run_bytes;
+            const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) a.ktiles * 1024 + lane * 8);
+            const size_t si = (size_t) ((a.ktiles * KTILE) >> a.group_shift) * a.n + col;
+            const float s = T16<T>::to_float(a.scales[si]);
+            const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
+            const uint4 w = make_uint4(hw.x, hw.y, 0, 0);
+            if constexpr (WBITS == 4)
+                gemv_tile_int4<T, 1, 2>(w, acc, &s, &z, [&](int st) { return afrag(a.ktiles, st); });
         }
-    }
-
-    // int4 with K % 128 == 64: the run ends with a 512-byte half tile (2 k-steps); wave 0 of the
-    // last k split takes it
-    if (half_tile && wave == 0)
-    {
-        const int kbase = a.ktiles * KTILE;
-        const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) a.ktiles * 1024 + lane * 8);
-        const size_t si = (size_t) (kbase >> a.group_shift) * a.n + col;
-        const float s = T16<T>::to_float(a.scales[si]);
-        const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
-        const uint4 w = make_uint4(hw.x, hw.y, 0, 0);
-        acc = gemv_step<T, 4, 0>(w, afrag(a.ktiles, 0), s, z, acc);
-        acc = gemv_step<T, 4, 1>(w, afrag(a.ktiles, 1), s, z, acc);
-    }
-
+        __syncthreads(); // the previous n-block's readers are done with `red`
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        red[(wave * 64 + lane) * 4 + r] = acc[r];
-    __syncthreads();
-
-    // 16 x 16 outputs: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
-    if (tid < 256)
-    {
-        const int om = tid >> 4, on = tid & 15;
-        const int src_lane = (om >> 2) * 16 + on, reg = om & 3;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWAVES; ++w)
-            v += red[(w * 64 + src_lane) * 4 + reg];
-        if (om < rows)
+        for (int r = 0; r < 4; ++r)
         {
-            const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
-            if (a.ksplit == 1)
+            red[(wave * 64 + lane) * 4 + r] = acc[r];
+            acc[r] = 0.f;
+        }
+        __syncthreads();
+        // 16 x 16 outputs: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+        if (tid < 256)
+        {
+            const int om = tid >> 4, on = tid & 15;
+            const int src_lane = (om >> 2) * 16 + on, reg = om & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w)
+                v += red[(w * 64 + src_lane) * 4 + reg];
+            if (om < rows)
             {
-                if (a.bias)
-                    v += T16<T>::to_float(a.bias[nb * 16 + on]);
-                a.out[oi] = T16<T>::from_float(v);
+                const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
+                if (a.ksplit == 1)
+                {
+                    if (a.bias)
+                        v += T16<T>::to_float(a.bias[nb * 16 + on]);
+                    a.out[oi] = T16<T>::from_float(v);
+                }
+                else
+                    a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = v;
             }
-            else
-                a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = v;
+        }
+    };
+
+    int c_nb = blockIdx.x, c_ck = 0; // chunk being computed (held by `ca` at the loop head)
+    while (c_nb < nblocks)
+    {
+        load_next(cb);
+        gemv_compute_chunk<T, WBITS, CH, NSZ>(ca, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
+        if (++c_ck == cpw)
+        {
+            flush(c_nb);
+            c_ck = 0;
+            c_nb += nb_stride;
+        }
+        if (c_nb >= nblocks)
+            break;
+        load_next(ca);
+        gemv_compute_chunk<T, WBITS, CH, NSZ>(cb, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
+        if (++c_ck == cpw)
+        {
+            flush(c_nb);
+            c_ck = 0;
+            c_nb += nb_stride;
         }
     }
 }
@@ -470,17 +560,66 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
     return a;
 }
 
-template <typename T, int WBITS, bool ZERO, int NWAVES, bool LDS_A>
+// Launch geometry of the decode kernel (see woq_gemv_kernel).
+struct GemvPlan
+{
+    int ksplit, nwaves, ch, ngroups;
+    size_t lds_bytes;
+};
+
+constexpr int GEMV_CUS = 256;
+constexpr size_t GEMV_LDS_MAX = 160 * 1024 - 512;
+
+size_t gemv_lds_bytes(int m, int k, int ktile, int ktiles, int ksplit, int nwaves)
+{
+    const int seg = (ktiles + std::max(1, ksplit) - 1) / std::max(1, ksplit);
+    const int krange = seg * ktile + (k - ktiles * ktile); // + the int4 half tile
+    return (size_t) nwaves * 64 * 4 * sizeof(float) + (size_t) std::min(16, m) * (krange * 2 + 32);
+}
+
+GemvPlan plan_gemv(int m, int n, int k, int wbits)
+{
+    const int ktile = wbits == 4 ? 128 : 64;
+    const int ktiles = k / ktile;
+    const int nblocks = n / 16, mchunks = std::max(1, (m + 15) / 16);
+    GemvPlan p{};
+    p.nwaves = 16; // one 16-wave block per CU: all of a CU's waves finish an n-block together
+    // k segments: (a) the activation slab of a segment must fit LDS, (b) when the n-blocks alone leave
+    // most CUs idle, split K across blocks (fp32 slabs + a reduce launch, so only if really idle)
+    int ks = 1;
+    while (ks < ktiles && gemv_lds_bytes(m, k, ktile, ktiles, ks, p.nwaves) > GEMV_LDS_MAX)
+        ++ks;
+    const int wgs = nblocks * mchunks;
+    if (wgs < GEMV_CUS / 2)
+    {
+        int fill = (GEMV_CUS + wgs - 1) / wgs;
+        fill = std::min(fill, std::max(1, ktiles / 16)); // keep >= 16 tiles per block
+        ks = std::max(ks, std::min(fill, 16));
+    }
+    const int seg = std::max(1, (ktiles + ks - 1) / ks);
+    p.ksplit = std::max(1, (ktiles + seg - 1) / seg); // no empty trailing segment
+    const int tpw = (seg + p.nwaves - 1) / p.nwaves;
+    p.ch = tpw >= 4 ? 4 : 2;
+    // n-groups: one block per CU, n-blocks dealt round-robin, every block the same count (+-1)
+    const int slots = std::max(1, GEMV_CUS / (mchunks * p.ksplit));
+    const int iters = (nblocks + slots - 1) / slots;
+    p.ngroups = (nblocks + iters - 1) / iters;
+    p.lds_bytes = gemv_lds_bytes(m, k, ktile, ktiles, p.ksplit, p.nwaves);
+    MQ_CHECK(p.lds_bytes <= GEMV_LDS_MAX, "k=%d too large for the decode kernel's LDS activation slab", k);
+    return p;
+}
+
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH>
 void launch_gemv_variant(const WoqArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     // two (scale, zero) pairs per tile only when a 128-row int4 tile spans two groups of 64
     const bool split = WBITS == 4 && a.group == 64;
-    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, LDS_A, (WBITS == 4 ? 2 : 1)>
-                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, LDS_A, 1>;
+    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1)>
+                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1>;
     if (lds_bytes > 64 * 1024)
     {
         MQ_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) GEMV_LDS_MAX));
     }
     hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), lds_bytes, stream, a);
 }
@@ -488,26 +627,23 @@ void launch_gemv_variant(const WoqArgs& a, dim3 grid, size_t lds_bytes, hipStrea
 template <typename T, int WBITS, bool ZERO>
 void launch_gemv(const WoqArgs& a, hipStream_t stream)
 {
-    dim3 grid(a.n / 16, (a.m + 15) / 16, a.ksplit);
-    constexpr int KTILE = Geo<WBITS>::KTILE;
-    const int per = (a.ktiles + a.ksplit - 1) / a.ksplit;
-    const int krange = per * KTILE + (WBITS == 4 ? (a.k & 127) : 0);
-    const size_t red_bytes = 8 * 64 * 4 * sizeof(float);
-    const size_t a_bytes = (size_t) std::min(16, a.m) * (krange * 2 + 32);
-    // activation rows in LDS when they fit beside a second resident block (<= 72 KiB), or, for a
-    // taller slab, when one block per CU is all the grid asks for anyway
-    const bool lds_a = red_bytes + a_bytes <= 72 * 1024
-        || (red_bytes + a_bytes <= 150 * 1024 && grid.x * grid.y * grid.z <= 320);
-    // 8 waves when a block owns enough tiles to keep them all busy
-    const bool w8 = per >= 32;
-    if (lds_a && w8)
-        launch_gemv_variant<T, WBITS, ZERO, 8, true>(a, grid, red_bytes + a_bytes, stream);
-    else if (lds_a)
-        launch_gemv_variant<T, WBITS, ZERO, 4, true>(a, grid, red_bytes + a_bytes, stream);
-    else if (w8)
-        launch_gemv_variant<T, WBITS, ZERO, 8, false>(a, grid, red_bytes, stream);
+    const GemvPlan p = plan_gemv(a.m, a.n, a.k, WBITS);
+    MQ_CHECK(p.ksplit == a.ksplit || a.ksplit == 1, "internal: plan mismatch");
+    GemvPlan q = p;
+    if (a.ksplit != p.ksplit) // no workspace for the slabs: one segment (must still fit LDS)
+    {
+        q.ksplit = 1;
+        q.lds_bytes = gemv_lds_bytes(a.m, a.k, Geo<WBITS>::KTILE, a.ktiles, 1, p.nwaves);
+        MQ_CHECK(q.lds_bytes <= GEMV_LDS_MAX,
+            "this m/k needs the split-K workspace (mi355q_weight_only_gemm_workspace_size)");
+        const int tpw = (a.ktiles + p.nwaves - 1) / p.nwaves;
+        q.ch = tpw >= 4 ? 4 : 2;
+    }
+    dim3 grid(q.ngroups, (a.m + 15) / 16, q.ksplit);
+    if (q.ch == 4)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 4>(a, grid, q.lds_bytes, stream);
     else
-        launch_gemv_variant<T, WBITS, ZERO, 4, false>(a, grid, red_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2>(a, grid, q.lds_bytes, stream);
     if (a.ksplit > 1)
     {
         const size_t total = (size_t) a.m * a.n;
@@ -540,17 +676,9 @@ void launch_dequant(const WoqArgs& a, hipStream_t stream)
 
 } // namespace
 
-// Split-K heuristic: only when the n-blocks alone leave most of the chip idle -- the reduce is a
-// second launch and costs more than a half-empty grid does.
 int woq_choose_ksplit(int m, int n, int k, int weight_type)
 {
-    const int ktiles = k / (weight_type == MI355Q_WEIGHT_INT4 ? 128 : 64);
-    const int wgs = (n / 16) * ((m + 15) / 16);
-    if (wgs >= 128)
-        return 1;
-    int s = (256 + wgs - 1) / wgs;
-    s = std::min(s, std::max(1, ktiles / 16)); // keep >= 16 tiles per block
-    return std::max(1, std::min(s, 16));
+    return plan_gemv(m, n, k, weight_type == MI355Q_WEIGHT_INT4 ? 4 : 8).ksplit;
 }
 
 size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)

@@ -80,9 +80,9 @@ def test_gfx950_layout_roundtrip_and_fragment_order(tq, bits, K):
         if bits == 4:
             half = kt == K // 128
             byte = nb * run + kt * 1024 + (lane * 8 if half else lane * 16) + s * 4
-            b = int(raw[byte + j // 2])
-            v = (b >> 4) if j & 1 else (b & 0xF)
-            v = v - 16 if v >= 8 else v
+            pos = 2 * j if j < 4 else 2 * (j - 4) + 1  # rows 0..3 -> low nibbles, rows 4..7 -> high nibbles
+            b = int(raw[byte + pos // 2])
+            v = ((b >> 4) if pos & 1 else (b & 0xF)) - 8  # stored biased: u = q + 8
         else:
             v = int(raw[nb * run + kt * 1024 + lane * 16 + (s * 2 + j // 4) * 4 + j % 4])
             v = v - 256 if v >= 128 else v
