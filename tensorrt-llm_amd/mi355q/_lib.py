@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libmi355q.so"))
+LIB_PATH = os.environ.get("MI355Q_LIB") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libmi355q.so"))
 
 # nvinfer1::DataType codes
 FLOAT, HALF, INT8, INT32, BOOL, UINT8, FP8, BF16, INT64 = range(9)
