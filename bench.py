@@ -222,14 +222,25 @@ def main():
                          "kernel": "decode_attn_kernel<bf16, kv=bf16, Dh=128, G=1, U=8>",
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": per_launch * 1e6},
         }
+        # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+        # this same command; KiB units, read side doubled on gfx950 as MI355X_MICROARCH.md prescribes):
+        # recorded by tools/run_round.sh into profiles/, read back here so the JSON line carries it
+        tfile = os.path.join(_ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                tj = json.load(f)
+            res["roofline"]["traffic"] = tj.get("decode_attn_kernel_bytes_per_launch")
+            res["roofline"]["traffic_source"] = tj.get("source")
         if not args.no_secondary:
             sec = {}
             try:
                 sec["w4a16_gemv"] = [bench_gemv(dev, 4 * 72, m=1), bench_gemv(dev, 4 * 72, m=1, pre_quant=True),
                                      bench_gemv(dev, 4 * 72, m=16),
                                      bench_gemv(dev, 2 * 72, m=1, n=11008, k=4096, sets=24),
-                                     bench_gemv(dev, 2 * 72, m=1, n=4096, k=11008, sets=24)]
-                sec["int8_gemm"] = bench_int8_gemm(dev, 10)
+                                     bench_gemv(dev, 2 * 72, m=1, n=4096, k=11008, sets=24),
+                                     bench_gemv(dev, 48, m=1, n=28672, k=8192, sets=6),
+                                     bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6)]
+                sec["int8_gemm"] = [bench_int8_gemm(dev, 10), bench_int8_gemm(dev, 10, n=5120, k=13824)]
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)
             res["secondary"] = sec

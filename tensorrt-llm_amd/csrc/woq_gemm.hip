@@ -258,14 +258,17 @@ __device__ __forceinline__ void gemv_compute_chunk(
 #pragma unroll
     for (int i = 0; i < CH; ++i)
     {
-        const bool live = kt0 + i < kt_end; // wave-uniform; a dead tile gets scale = zero = 0 -> W = 0
-        const int kt = min(kt0 + i, kt_last);
+        // wave-uniform branch: a tile past the wave's range holds unrelated weights and its
+        // activation fragment may lie outside the staged LDS slab (NaN garbage), so it is skipped
+        if (kt0 + i >= kt_end)
+            continue;
+        const int kt = kt0 + i;
         float s[2], z[2];
 #pragma unroll
         for (int h = 0; h < NSZ; ++h)
         {
-            s[h] = live ? T16<T>::to_float(c.s[i][h]) : 0.f;
-            z[h] = live ? T16<T>::to_float(c.z[i][h]) : 0.f;
+            s[h] = T16<T>::to_float(c.s[i][h]);
+            z[h] = T16<T>::to_float(c.z[i][h]);
         }
         if constexpr (WBITS == 4)
             gemv_tile_int4<T, NSZ, 4>(c.w[i], acc, s, z, [&](int st) { return afrag(kt, st); });
