@@ -18,6 +18,21 @@ int woq_choose_ksplit(int m, int n, int k, int weight_type);
 size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type);
 void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream);
 void weight_only_dequantize(const mi355q_weight_only_params& p, hipStream_t stream);
+
+// woq_prefill.hip
+struct WoqArgsHost
+{
+    const uint8_t* qweight;
+    const uint16_t *scales, *zeros, *act, *bias;
+    uint16_t* out;
+    int m, n, k, group, group_shift, ktiles;
+    bool bf16, int4;
+    float* slabs; // fp32 [ksplit][m][n] workspace, or null (then no split-K)
+};
+bool woq_prefill_supported(int m, int n, int k);
+int woq_prefill_ksplit(int m, int n, int k, int weight_type);
+void woq_splitk_reduce(const float* slabs, const void* bias, void* out, int m, int n, int ksplit, bool bf16, hipStream_t stream);
+void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream);
 void apply_per_channel_scale(
     void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream);
 // plugins.cpp: smoothing (if act_scale) + GEMM, carving p.workspace

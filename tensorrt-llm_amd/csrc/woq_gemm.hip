@@ -18,7 +18,7 @@
 //     dequant costs ~2.8 VALU instructions per weight, so all 256 CUs must take part (N/16 blocks);
 //   * optional split-K across workgroups (fp32 slabs in the workspace + a tiny reduce kernel) when
 //     N/16 workgroups cannot fill the chip.
-#include "kernels.h"
+#include "woq_common.h"
 #include <cstdlib>
 
 namespace mi355q
@@ -27,150 +27,6 @@ namespace mi355q
 namespace
 {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-
-struct WoqArgs
-{
-    const uint8_t* qweight;
-    const uint16_t* scales;
-    const uint16_t* zeros;
-    const uint16_t* act;
-    const uint16_t* bias;
-    uint16_t* out;
-    float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1
-    int m, n, k;
-    int group;  // group size in k; == k for per-channel
-    int group_shift; // log2(group); 31 for per-channel (k >> 31 == 0)
-    int ktiles; // full k-tiles: k / KTILE
-    int ksplit;
-};
-
-template <typename T>
-__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
-template <>
-__device__ __forceinline__ f32x4_t mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4_t c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-        __builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b, f32x4_t c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(
-        __builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float sbyte(uint32_t w, int i)
-{
-    return (float) (int8_t) (w >> (8 * i)); // v_cvt_f32_i32_sdwa sext(BYTE_i)
-}
-
-// GFX950 int4 dword (preprocess.cpp Gfx950Map): element j of the lane's 8-row fragment is stored
-// biased (u = q + 8) at nibble j < 4 ? 2j : 2(j-4)+1, i.e. `w & 0x0f0f0f0f` holds elements 0..3 as
-// bytes and `(w >> 4) & 0x0f0f0f0f` elements 4..7.
-//
-// Exact dequantisation: 8 int4 -> 8 values round16(fma(q, scale, zero)) (4 packed dwords).
-// After the xor the nibbles are two's complement again; lo/hi bytes carry 16*q exactly, so the fma
-// uses scale/16 (a power-of-two rescale: exact).
-template <typename T>
-__device__ __forceinline__ uint4 dequant8_int4(uint32_t w, float s16, float z)
-{
-    w ^= 0x88888888u;
-    const uint32_t lo = (w << 4) & 0xf0f0f0f0u; // byte i = 16 * q[i]
-    const uint32_t hi = w & 0xf0f0f0f0u;        // byte i = 16 * q[4+i]
-    uint4 r;
-    r.x = pack2<T>(fmaf(sbyte(lo, 0), s16, z), fmaf(sbyte(lo, 1), s16, z));
-    r.y = pack2<T>(fmaf(sbyte(lo, 2), s16, z), fmaf(sbyte(lo, 3), s16, z));
-    r.z = pack2<T>(fmaf(sbyte(hi, 0), s16, z), fmaf(sbyte(hi, 1), s16, z));
-    r.w = pack2<T>(fmaf(sbyte(hi, 2), s16, z), fmaf(sbyte(hi, 3), s16, z));
-    return r;
-}
-
-// Integer-domain unpack for the decode GEMV: 8 biased int4 -> the 8 integers u = 0..15 as exact
-// 16-bit floats.  A byte 0x00..0x0f read as OCP e4m3 is u * 2^-9 (denormals 0..7, then exponent 1),
-// so v_cvt_scalef32_pk_{bf16,f16}_fp8 with scale 2^9 converts two nibbles per instruction:
-// 3 mask/shift + 4 convert VALU ops per 8 weights instead of 23 for the exact dequantisation.
-template <typename T>
-__device__ __forceinline__ uint32_t cvt2_u4(uint32_t bytes, bool hi_word);
-template <>
-__device__ __forceinline__ uint32_t cvt2_u4<bf16_t>(uint32_t bytes, bool hi_word)
-{
-    return hi_word ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(bytes, 512.f, true))
-                   : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(bytes, 512.f, false));
-}
-template <>
-__device__ __forceinline__ uint32_t cvt2_u4<f16_t>(uint32_t bytes, bool hi_word)
-{
-    return hi_word ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(bytes, 512.f, true))
-                   : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(bytes, 512.f, false));
-}
-
-template <typename T>
-__device__ __forceinline__ uint4 unpack8_u4(uint32_t w)
-{
-    const uint32_t lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
-    uint4 r;
-    r.x = cvt2_u4<T>(lo, false);
-    r.y = cvt2_u4<T>(lo, true);
-    r.z = cvt2_u4<T>(hi, false);
-    r.w = cvt2_u4<T>(hi, true);
-    return r;
-}
-
-// sixteen 1.0s: the B operand that turns an MFMA into the row sums of A
-template <typename T>
-__device__ __forceinline__ uint4 ones8()
-{
-    constexpr uint32_t one2 = T16<T>::is_bf16 ? 0x3f803f80u : 0x3c003c00u;
-    return make_uint4(one2, one2, one2, one2);
-}
-
-// 8 signed int8 (two dwords) -> 8 dequantised 16-bit values
-template <typename T>
-__device__ __forceinline__ uint4 dequant8_int8(uint32_t w0, uint32_t w1, float s, float z)
-{
-    uint4 r;
-    r.x = pack2<T>(fmaf(sbyte(w0, 0), s, z), fmaf(sbyte(w0, 1), s, z));
-    r.y = pack2<T>(fmaf(sbyte(w0, 2), s, z), fmaf(sbyte(w0, 3), s, z));
-    r.z = pack2<T>(fmaf(sbyte(w1, 0), s, z), fmaf(sbyte(w1, 1), s, z));
-    r.w = pack2<T>(fmaf(sbyte(w1, 2), s, z), fmaf(sbyte(w1, 3), s, z));
-    return r;
-}
-
-template <int WBITS>
-struct Geo
-{
-    static constexpr int KTILE = WBITS == 4 ? 128 : 64;
-    static constexpr int KSTEPS = KTILE / 32;      // MFMA k-steps per tile (4 or 2)
-    static constexpr int NSZ = WBITS == 4 ? 2 : 1; // (scale, zero) pairs a tile may span (group 64 on int4)
-};
-
-// k-step ST of the lane fragment `w` -> dequantised B operand.  s / z: this k-step's group.
-template <typename T, int WBITS, int ST>
-__device__ __forceinline__ uint4 dequant_step(const uint4& w, float s, float z)
-{
-    const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w);
-    if constexpr (WBITS == 4)
-        return dequant8_int4<T>(wd[ST], s * 0.0625f, z);
-    else
-        return dequant8_int8<T>(wd[ST * 2], wd[ST * 2 + 1], s, z);
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-
-// SRD over `bytes` bytes at p (wave-uniform inputs only, so hipcc never wraps the loads in a
-// waterfall loop); out-of-range offsets return 0.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes)
-{
-    const uint64_t u = (uint64_t) p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) u);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (u >> 32));
-    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t) (bytes > 0xffffffffull ? 0xffffffffull : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc((void*) (((uint64_t) hi << 32) | lo), 0, nb, 0x00020000);
-}
 
 // The weight side of CH consecutive k-tiles of one n-block, issued as one burst of independent,
 // branch-free buffer loads: per-lane byte offset in a VGPR (set once), the tile / group offset in an
@@ -690,11 +546,24 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
     size_t best = 0;
     for (int mm = 1; mm <= m; mm = mm < 16 ? mm + 1 : mm + 16)
     {
-        const int s = woq_choose_ksplit(mm, n, k, weight_type);
+        const int s = woq_prefill_supported(mm, n, k) ? woq_prefill_ksplit(mm, n, k, weight_type)
+                                                        : woq_choose_ksplit(mm, n, k, weight_type);
         if (s > 1)
             best = std::max(best, (size_t) s * mm * n * sizeof(float));
     }
     return best;
+}
+
+void woq_splitk_reduce(const float* slabs, const void* bias, void* out, int m, int n, int ksplit, bool bf16, hipStream_t stream)
+{
+    const size_t total = (size_t) m * n;
+    const dim3 grid((unsigned) ((total + 255) / 256));
+    if (bf16)
+        hipLaunchKernelGGL((woq_splitk_reduce_kernel<bf16_t>), grid, dim3(256), 0, stream, slabs,
+            (const uint16_t*) bias, (uint16_t*) out, m, n, ksplit);
+    else
+        hipLaunchKernelGGL((woq_splitk_reduce_kernel<f16_t>), grid, dim3(256), 0, stream, slabs,
+            (const uint16_t*) bias, (uint16_t*) out, m, n, ksplit);
 }
 
 void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream)
@@ -704,6 +573,21 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
     if (p.m == 0)
         return;
     MQ_CHECK(p.act_scale == nullptr, "pre-quant scale must be applied with mi355q_apply_per_channel_scale first");
+    if (woq_prefill_supported(p.m, p.n, p.k) && !std::getenv("MI355Q_NO_PREFILL"))
+    {
+        // m > 16: dequantise-in-registers MFMA GEMM (woq_prefill.hip); the decode kernel below would
+        // stream the weights once per 16 rows
+        const int ks = woq_prefill_ksplit(p.m, p.n, p.k, p.weight_type);
+        const size_t need = (size_t) ks * p.m * p.n * sizeof(float);
+        float* slabs = (ks > 1 && workspace && workspace_bytes >= need) ? reinterpret_cast<float*>(workspace) : nullptr;
+        WoqArgsHost h{a.qweight, a.scales, a.zeros, a.act, a.bias, a.out, a.m, a.n, a.k, a.group, a.group_shift, a.ktiles,
+            p.act_type == MI355Q_BF16, p.weight_type == MI355Q_WEIGHT_INT4, slabs};
+        weight_only_prefill_gemm(h, stream);
+        if (slabs)
+            woq_splitk_reduce(slabs, p.bias, p.out, p.m, p.n, ks, p.act_type == MI355Q_BF16, stream);
+        MQ_HIP(hipGetLastError());
+        return;
+    }
     a.ksplit = woq_choose_ksplit(p.m, p.n, p.k, p.weight_type);
     if (a.ksplit > 1)
     {

@@ -1,0 +1,356 @@
+// woq_prefill.hip -- weight-only quantized GEMM for prefill-sized M (m > 16): fp16|bf16 activations x
+// int4|int8 weights, dequantised in registers and fed to v_mfma_f32_16x16x32_{bf16,f16}.  Replaces
+//   kernels/cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm.h:54-137 (CutlassFpAIntBGemmRunner::gemm, the
+//   dequant-in-mainloop tensor-op GEMM the plugins pick for m >= 5).
+// Design (MFMA-bound):
+//   * output tile TM (= MT*16: 32 / 64 / 128 rows of m) x TN (= NB*64: 128 / 256 columns) per workgroup
+//     of 4 waves; wave w owns the NB 16-column n-blocks NB*w .. NB*w+NB-1 of the tile and ALL its m
+//     rows, so every weight is dequantised exactly once per workgroup (23 VALU ops per 8 weights) and
+//     reused by MT MFMAs, and every activation fragment read from LDS feeds NB MFMAs (NB = 4 keeps the
+//     LDS read pipe at half the MFMA pipe's time; NB = 2 would tie them);
+//   * optional split-K over grid.y for small m (few output tiles): fp32 slabs + the reduce kernel of
+//     woq_gemm.hip;
+//   * weights come straight from the GFX950 layout (preprocess.cpp) into registers -- one 16-byte load
+//     per lane is the fragment of a whole k-tile, no LDS, double-buffered one k-tile ahead;
+//   * dequantisation is the bit-exact one: w = round16(fma(q, scale, zero)) (woq_common.h), i.e. the MFMA
+//     consumes exactly the values mi355q_weight_only_dequantize returns;
+//   * the activation tile [TM][k-tile] goes through an LDS double buffer filled by LDS-DMA
+//     (global_load_lds_dwordx4; the XOR swizzle is applied to the per-lane source address so that the
+//     16 rows x one 16-byte chunk of a ds_read_b128 fragment cover all 64 banks once);
+//   * the dequantised weights are the MFMA *A* operand and the activations the *B* operand, so a lane
+//     ends up with 4 consecutive output columns of one row: 8-byte stores, bias fused.
+#include "woq_common.h"
+#include <algorithm>
+
+namespace mi355q
+{
+
+namespace
+{
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+constexpr int PF_WAVES = 4;
+
+struct PrefillPlan
+{
+    int mt, nb, ksplit;
+};
+
+PrefillPlan plan_prefill(int m, int n, int k, int wbits)
+{
+    PrefillPlan p{};
+    p.mt = m <= 32 ? 2 : (m <= 64 ? 4 : 8);
+    const int tiles_m = (m + p.mt * 16 - 1) / (p.mt * 16);
+    // 256-column tiles (4 n-blocks per wave) once they alone fill the chip; else 128 columns
+    p.nb = (p.mt == 8 && n % 256 == 0 && tiles_m * (n / 256) >= 256) ? 4 : 2;
+    const int wgs = tiles_m * (n / (p.nb * 64));
+    const int nk = (k + (wbits == 4 ? 127 : 63)) / (wbits == 4 ? 128 : 64);
+    // split K while the output tiles leave most CUs idle (fp32 slabs + reduce launch): >= 4 k-tiles per split
+    int ks = 1;
+    if (wgs < 256)
+        ks = std::max(1, std::min(std::min((512 + wgs - 1) / wgs, nk / 4), 16));
+    const int per = (nk + ks - 1) / ks;
+    p.ksplit = (nk + per - 1) / per;
+    return p;
+}
+
+// grid.x = tiles_m * tiles_n (remapped XCD-contiguous, m fastest: neighbours share the weight panel)
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB>
+__global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
+{
+    constexpr int PF_TN = NB * 16 * PF_WAVES;
+    constexpr int KTILE = Geo<WBITS>::KTILE;   // 128 (int4) / 64 (int8) rows of k per weight tile
+    constexpr int KSTEPS = Geo<WBITS>::KSTEPS; // MFMA k-steps per tile
+    constexpr int TM = MT * 16;
+    constexpr int RB = KTILE * 2;              // bytes per activation row in LDS: 256 / 128
+    constexpr int CHUNKS = RB / 16;            // 16-byte chunks per row: 16 / 8
+    constexpr int ROWS_PER_DMA = 1024 / RB;    // 4 / 8
+    constexpr int BUF_BYTES = TM * RB;
+    constexpr int DMA_PER_TILE = BUF_BYTES / 1024;
+    constexpr int DMA_PER_WAVE = (DMA_PER_TILE + PF_WAVES - 1) / PF_WAVES;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * TM, n0 = tn * PF_TN;
+
+    // swizzle of the 16-byte chunk index by row: 16 consecutive rows x one logical chunk -> 256 distinct bytes
+    auto sw = [](int row) { return CHUNKS == 16 ? (row & 15) : ((row >> 1) & 7); };
+
+    // ---- activation staging (LDS-DMA).  DMA d covers rows [d*ROWS_PER_DMA, +ROWS_PER_DMA); lane -> (row, stored chunk)
+    const int drow = lane / CHUNKS, dchunk = lane % CHUNKS;
+    const uint16_t* asrc[DMA_PER_WAVE];
+    int achunk[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i)
+    {
+        const int d = wave * DMA_PER_WAVE + i;
+        const int row = d * ROWS_PER_DMA + drow;
+        achunk[i] = dchunk ^ sw(row);
+        asrc[i] = a.act + (size_t) min(m0 + row, a.m - 1) * a.k; // rows past m re-read the last row; never stored
+    }
+    // k range of this workgroup (split-K over grid.y); the int4 half tile belongs to the last split
+    const bool half_tile = WBITS == 4 && (a.k & 127);
+    const int nk_all = a.ktiles + (half_tile ? 1 : 0);
+    const int per = (nk_all + a.ksplit - 1) / a.ksplit;
+    const int kt_lo = blockIdx.y * per;
+    const int nk = min(nk_all, kt_lo + per);
+    auto stage = [&](int kt, int buf)
+    {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i)
+        {
+            const int d = wave * DMA_PER_WAVE + i;
+            if (DMA_PER_TILE % PF_WAVES != 0 && d >= DMA_PER_TILE)
+                continue;
+            int kk = kt * KTILE + achunk[i] * 8;
+            if (kk >= a.k) // half tile: chunks past k are staged from a valid address and never read
+                kk = kt * KTILE;
+            __builtin_amdgcn_global_load_lds(
+                (gbl_void_t*) (asrc[i] + kk), (lds_void_t*) (lds + buf * BUF_BYTES + d * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- weights: this wave's two n-blocks, one k-tile per 16-byte load, one tile ahead
+    const size_t run_bytes = (size_t) a.k * 16 * WBITS / 8;
+    const int nb0 = (n0 >> 4) + wave * NB;
+    const uint8_t* run0 = a.qweight + (size_t) nb0 * run_bytes;
+    const int col0 = nb0 * 16 + (lane & 15);
+    struct WTile
+    {
+        uint4 w[NB];
+        uint16_t s[NB][NSZ], z[NB][NSZ];
+    };
+    auto load_w = [&](WTile& t, int kt)
+    {
+        const bool half = kt == a.ktiles; // 512-byte trailing half tile: 8 bytes per lane
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+        {
+            const uint8_t* run = run0 + (size_t) b * run_bytes;
+            if (half)
+            {
+                const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) kt * 1024 + lane * 8);
+                t.w[b] = make_uint4(hw.x, hw.y, 0, 0);
+            }
+            else
+                t.w[b] = *reinterpret_cast<const uint4*>(run + (size_t) kt * 1024 + lane * 16);
+#pragma unroll
+            for (int h = 0; h < NSZ; ++h)
+            {
+                const int k = min(kt * KTILE + h * 64, a.k - 1);
+                const size_t si = (size_t) (k >> a.group_shift) * a.n + col0 + b * 16;
+                t.s[b][h] = a.scales[si];
+                t.z[b][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
+            }
+        }
+    };
+
+    f32x4_t acc[NB][MT];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            acc[b][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    // per m-tile j the fragment row is j*16 + frow: sw(row) only depends on frow (CHUNKS == 16) or on
+    // frow and nothing else either ((row >> 1) & 7 with row = 16j + frow) -> hoisted
+    const int fsw = sw(frow);
+    const uint8_t* frag_base = lds + frow * RB;
+
+    WTile wt[2];
+    if (kt_lo < nk)
+    {
+        stage(kt_lo, 0);
+        load_w(wt[0], kt_lo);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto compute = [&](const WTile& t, int buf, int steps)
+    {
+        float s[NB][NSZ], z[NB][NSZ];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int h = 0; h < NSZ; ++h)
+            {
+                s[b][h] = T16<T>::to_float(t.s[b][h]);
+                z[b][h] = T16<T>::to_float(t.z[b][h]);
+            }
+        const uint8_t* sa = frag_base + buf * BUF_BYTES;
+#pragma unroll
+        for (int st = 0; st < KSTEPS; ++st)
+        {
+            if (st >= steps)
+                break;
+            constexpr int H1 = NSZ - 1;
+            const int h = (WBITS == 4 && st >= 2) ? H1 : 0;
+            uint4 wf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+            {
+                if (st == 0)
+                    wf[b] = dequant_step<T, WBITS, 0>(t.w[b], s[b][h], z[b][h]);
+                else if (st == 1)
+                    wf[b] = dequant_step<T, WBITS, 1>(t.w[b], s[b][h], z[b][h]);
+                else if (st == 2)
+                    wf[b] = dequant_step<T, WBITS, 2 % KSTEPS>(t.w[b], s[b][h], z[b][h]);
+                else
+                    wf[b] = dequant_step<T, WBITS, 3 % KSTEPS>(t.w[b], s[b][h], z[b][h]);
+            }
+            const int coff = ((st * 4 + fk) ^ fsw) << 4;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+            {
+                const uint4 av = *reinterpret_cast<const uint4*>(sa + j * 16 * RB + coff);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[b][j] = mfma16<T>(wf[b], av, acc[b][j]);
+            }
+        }
+    };
+
+    for (int kt = kt_lo; kt < nk; kt += 2)
+    {
+        // even tile of the range: buffers 0
+        if (kt + 1 < nk)
+        {
+            stage(kt + 1, 1);
+            load_w(wt[1], kt + 1);
+        }
+        compute(wt[0], 0, (kt == a.ktiles) ? 2 : KSTEPS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 >= nk)
+            break;
+        if (kt + 2 < nk)
+        {
+            stage(kt + 2, 0);
+            load_w(wt[0], kt + 2);
+        }
+        compute(wt[1], 1, (kt + 1 == a.ktiles) ? 2 : KSTEPS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
+    const int em = lane & 15, en = (lane >> 4) * 4;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+    {
+        const int n = (nb0 + b) * 16 + en;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias && a.ksplit == 1)
+        {
+            const uint2 bv = *reinterpret_cast<const uint2*>(a.bias + n);
+            bias[0] = T16<T>::lo(bv.x);
+            bias[1] = T16<T>::hi(bv.x);
+            bias[2] = T16<T>::lo(bv.y);
+            bias[3] = T16<T>::hi(bv.y);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+        {
+            const int m = m0 + j * 16 + em;
+            if (m >= a.m)
+                continue;
+            const size_t oi = (size_t) m * a.n + n;
+            if (a.ksplit == 1)
+                *reinterpret_cast<uint2*>(a.out + oi)
+                    = make_uint2(pack2<T>(acc[b][j][0] + bias[0], acc[b][j][1] + bias[1]),
+                        pack2<T>(acc[b][j][2] + bias[2], acc[b][j][3] + bias[3]));
+            else
+                *reinterpret_cast<float4*>(a.slabs + (size_t) blockIdx.y * a.m * a.n + oi)
+                    = make_float4(acc[b][j][0], acc[b][j][1], acc[b][j][2], acc[b][j][3]);
+        }
+    }
+}
+
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB>
+void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
+{
+    const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 64);
+    hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB>), dim3(tiles_m * tiles_n, a.ksplit),
+        dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);
+}
+
+template <typename T, int WBITS, bool ZERO>
+void launch_prefill(const WoqArgs& a, hipStream_t stream)
+{
+    constexpr int NSZ2 = WBITS == 4 ? 2 : 1;
+    const bool split = WBITS == 4 && a.group == 64;
+    const PrefillPlan p = plan_prefill(a.m, a.n, a.k, WBITS);
+#define MQ_PF(MTV, NBV)                                                                                                \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (split)                                                                                                     \
+            launch_prefill_mt<T, WBITS, ZERO, NSZ2, MTV, NBV>(a, stream);                                              \
+        else                                                                                                           \
+            launch_prefill_mt<T, WBITS, ZERO, 1, MTV, NBV>(a, stream);                                                 \
+    } while (0)
+    if (p.mt == 2)
+        MQ_PF(2, 2);
+    else if (p.mt == 4)
+        MQ_PF(4, 2);
+    else if (p.nb == 2)
+        MQ_PF(8, 2);
+    else
+        MQ_PF(8, 4);
+#undef MQ_PF
+}
+
+} // namespace
+
+bool woq_prefill_supported(int m, int n, int k)
+{
+    return m > 16 && n % 128 == 0 && k % 64 == 0;
+}
+
+int woq_prefill_ksplit(int m, int n, int k, int weight_type)
+{
+    return plan_prefill(m, n, k, weight_type == MI355Q_WEIGHT_INT4 ? 4 : 8).ksplit;
+}
+
+void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
+{
+    WoqArgs a{};
+    a.qweight = h.qweight;
+    a.scales = h.scales;
+    a.zeros = h.zeros;
+    a.act = h.act;
+    a.bias = h.bias;
+    a.out = h.out;
+    a.m = h.m;
+    a.n = h.n;
+    a.k = h.k;
+    a.group = h.group;
+    a.group_shift = h.group_shift;
+    a.ktiles = h.ktiles;
+    a.ksplit = h.slabs ? plan_prefill(h.m, h.n, h.k, h.int4 ? 4 : 8).ksplit : 1;
+    a.slabs = h.slabs;
+    const bool bf = h.bf16, i4 = h.int4, z = h.zeros != nullptr;
+    if (bf && i4 && z) launch_prefill<bf16_t, 4, true>(a, stream);
+    else if (bf && i4) launch_prefill<bf16_t, 4, false>(a, stream);
+    else if (bf && z) launch_prefill<bf16_t, 8, true>(a, stream);
+    else if (bf) launch_prefill<bf16_t, 8, false>(a, stream);
+    else if (i4 && z) launch_prefill<f16_t, 4, true>(a, stream);
+    else if (i4) launch_prefill<f16_t, 4, false>(a, stream);
+    else if (z) launch_prefill<f16_t, 8, true>(a, stream);
+    else launch_prefill<f16_t, 8, false>(a, stream);
+    MQ_HIP(hipGetLastError());
+}
+
+} // namespace mi355q
