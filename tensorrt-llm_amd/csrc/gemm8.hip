@@ -36,6 +36,7 @@ struct Gemm8Args
     int per_token, per_channel;
     int m, n, k;
     int out_type;
+    int ldc; // row stride of C in elements (== n unless this is a column slice of a wider output)
 };
 
 template <bool FP8>
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm8_kernel(Gemm8Args g)
                 if (row >= g.m)
                     continue;
                 const float sr = g.alpha_row[g.per_token ? row : 0];
-                store_out(g.C, g.out_type, (size_t) row * g.n + col, (float) acc[i][j][r] * (sc * sr));
+                store_out(g.C, g.out_type, (size_t) row * g.ldc + col, (float) acc[i][j][r] * (sc * sr));
             }
         }
 }
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm8_big_kernel(Gemm8Args g, in
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 v[r] = (float) acc[i][j][r] * (g.alpha_col[g.per_channel ? col + r : 0] * sr);
-            const size_t idx = row * g.n + col;
+            const size_t idx = row * g.ldc + col;
             switch (g.out_type)
             {
             case MI355Q_HALF:
@@ -351,13 +352,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm8_big_kernel(Gemm8Args g, in
     }
 }
 
-// Tile choice: fewest "rounds" of the 256 CUs weighted by how efficient each tile shape runs.
-struct BigTile
-{
-    int tm, tn, blocks_per_cu;
-    float eff;
-};
-
 template <int TM, int TN, int WM, int WN>
 void launch_big(const Gemm8Args& g, hipStream_t stream)
 {
@@ -366,37 +360,347 @@ void launch_big(const Gemm8Args& g, hipStream_t stream)
         tiles_m, tiles_n);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Phased 256 x 256 kernel (the main int8 path): 8 waves = 2 (m) x 4 (n), wave tile 128 x 64,
+// K-tile 128 bytes, ONE block per CU (128 KiB LDS, ~230 VGPRs).  At one block per CU nothing hides a
+// drained load queue, so the LDS-DMA stream is never drained:
+//   * a K-tile is staged as four 16 KiB units -- U1 / U4: the activation rows of every wave's first /
+//     second 64-row quadrant; U2 / U3: the weight rows of every wave's first / second 32-column
+//     quadrant -- into 2 x 4 LDS slots; each wave issues 2 DMAs per unit;
+//   * a K-tile is 4 phases (one 64 x 32 accumulator quadrant each: 16 MFMAs): phase 1 reads the U1
+//     fragments (8 ds_read_b128), phase 2 the U3 fragments (4), phase 3 the U4 fragments (8), phase 4
+//     the NEXT tile's U2 fragments (4); the fragments of the other operand stay in registers;
+//   * every phase also issues the DMAs of ONE unit, 5-6 phases before its first use:
+//        phase 3 -> U1 of tile t+2, phase 4 -> U2 of t+2, phase 1 -> U3 of t+1, phase 2 -> U4 of t+1
+//     (a slot is re-staged no earlier than two phases after the phase that read it), followed by a
+//     COUNTED s_waitcnt vmcnt(8): this wave's DMAs of the unit(s) the NEXT phase reads have landed,
+//     4 units stay in flight across the barriers (raw s_barrier: __syncthreads would drain them);
+//   * a phase is [ds_reads + DMAs + counted wait] s_barrier [lgkmcnt(0); 16 MFMAs at raised priority]
+//     s_barrier, and the m = 1 wave group runs one barrier behind the m = 0 group, so one group's LDS
+//     reads overlap the other group's MFMAs on every SIMD.
+// Synchronisation argument: a unit read in phase p was waited for (by every wave, for its own DMAs)
+// in phase p-1's first half, and both groups pass the barrier that ends interval 2p-1 before either
+// reads it (RAW); the last read of a slot retires at the latest in the interval after the late
+// group's read (2p+2) and the earliest re-stage is two phases later (intervals 2p+4 / 2p+5) (WAR).
+// Requires m % 256 == 0, n % 256 == 0, k % 128 == 0.
+__global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tiles_m, int tiles_n)
+{
+    constexpr int TK = 128;
+    constexpr int UNIT = 128 * TK;                                       // 16 KiB
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * UNIT]; // [buffer][unit U1..U4]; the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const size_t m0 = (size_t) tm * 256, n0 = (size_t) tn * 256;
+    const int nk = g.k / TK;
+
+    // ---- staging: unit row u (0..127), DMA d = wave*2 + i covers unit rows [8d, 8d+8); lane -> (row, stored chunk).
+    // stored chunk c' of row u holds source chunk c' ^ ((u >> 1) & 7)
+    const uint8_t* usrc[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        const int u = (wave * 2 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((u >> 1) & 7);
+        const size_t ra = m0 + (u >> 6) * 128 + (u & 63); // activation row of U1 (U4: + 64)
+        const size_t rb = n0 + (u >> 5) * 64 + (u & 31);  // weight row of U2 (U3: + 32)
+        usrc[0][i] = g.A + ra * g.k + chunk * 16;
+        usrc[3][i] = g.A + (ra + 64) * g.k + chunk * 16;
+        usrc[1][i] = g.B + rb * g.k + chunk * 16;
+        usrc[2][i] = g.B + (rb + 32) * g.k + chunk * 16;
+    }
+    // tiles past the end are clamped to the last one: their slots are never read again, and the
+    // number of DMAs in flight (the vmcnt arithmetic) stays the same to the last phase
+    auto stage = [&](int unit, int kt)
+    {
+        const int t = min(kt, nk - 1);
+        uint8_t* dst = lds + ((kt & 1) * 4 + unit) * UNIT + wave * 2048;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*) (usrc[unit][0] + (size_t) t * TK), (lds_void_t*) dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (gbl_void_t*) (usrc[unit][1] + (size_t) t * TK), (lds_void_t*) (dst + 1024), 16, 0, 0);
+    };
+
+    // ---- fragments: lane -> row (l & 15) of a 16-row tile, 16-byte chunk (l >> 4) + 4*ks
+    const int frow = lane & 15, fk = lane >> 4;
+    const int fsw = (frow >> 1) & 7;
+    const int off_k0 = frow * TK + ((fk ^ fsw) << 4), off_k1 = frow * TK + (((4 + fk) ^ fsw) << 4);
+    const int a_row0 = wr * 64 * TK; // this wave's rows inside U1 / U4
+    const int b_row0 = wc * 32 * TK; // inside U2 / U3
+
+    i32x4_t acc[8][4]; // [m-tile of the wave (2 quadrants x 4)][n-tile (2 quadrants x 2)]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = i32x4_t{0, 0, 0, 0};
+    i32x4_t fa[4][2], fb0[2][2], fb1[2][2], fb0n[2][2]; // activation quadrant, weight quadrants 0 / 1 (+ next tile's 0): [tile][ks]
+
+    auto read_a = [&](const uint8_t* unit_base)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            fa[i][0] = *reinterpret_cast<const i32x4_t*>(unit_base + a_row0 + i * 16 * TK + off_k0);
+            fa[i][1] = *reinterpret_cast<const i32x4_t*>(unit_base + a_row0 + i * 16 * TK + off_k1);
+        }
+    };
+    auto read_b = [&](i32x4_t (&fb)[2][2], const uint8_t* unit_base)
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+        {
+            fb[j][0] = *reinterpret_cast<const i32x4_t*>(unit_base + b_row0 + j * 16 * TK + off_k0);
+            fb[j][1] = *reinterpret_cast<const i32x4_t*>(unit_base + b_row0 + j * 16 * TK + off_k1);
+        }
+    };
+    auto mfma_quadrant = [&](int mq, int nq, const i32x4_t (&fb)[2][2])
+    {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mq * 4 + i][nq * 2 + j]
+                        = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j][ks], fa[i][ks], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define P8_BARRIER()                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+    } while (0)
+#define P8_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define P8_WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    // prologue: all of tile 0, U1 + U2 of tile 1 (U3 / U4 of tile 1 are staged by tile 0's phases 1 / 2)
+    stage(0, 0);
+    stage(1, 0);
+    stage(2, 0);
+    stage(3, 0);
+    stage(0, 1);
+    stage(1, 1);
+    P8_WAIT_VM8(); // U1, U2 of tile 0 (4 units issued after them)
+    P8_BARRIER();
+    if (wr == 1)
+        P8_BARRIER(); // the m = 1 group runs one barrier behind
+
+    read_b(fb0, lds + 1 * UNIT); // U2 of tile 0 (in the loop it is read one phase ahead, in phase 4)
+    for (int kt = 0; kt < nk; ++kt)
+    {
+        const uint8_t* buf = lds + (kt & 1) * 4 * UNIT;
+        const uint8_t* nbuf = lds + ((kt + 1) & 1) * 4 * UNIT;
+        // phase 1: 8 fragment reads
+        read_a(buf + 0 * UNIT);
+        stage(2, kt + 1);
+        P8_WAIT_VM8(); // U3 of this tile
+        P8_BARRIER();
+        P8_WAIT_LGKM0();
+        mfma_quadrant(0, 0, fb0);
+        P8_BARRIER();
+        // phase 2: 4 reads
+        read_b(fb1, buf + 2 * UNIT);
+        stage(3, kt + 1);
+        P8_WAIT_VM8(); // U4 of this tile
+        P8_BARRIER();
+        P8_WAIT_LGKM0();
+        mfma_quadrant(0, 1, fb1);
+        P8_BARRIER();
+        // phase 3: 8 reads
+        read_a(buf + 3 * UNIT);
+        stage(0, kt + 2);
+        P8_WAIT_VM6(); // U2 of the next tile (read in phase 4)
+        P8_BARRIER();
+        P8_WAIT_LGKM0();
+        mfma_quadrant(1, 1, fb1);
+        P8_BARRIER();
+        // phase 4: 4 reads -- the next tile's weight quadrant 0, so that no phase carries 12
+        read_b(fb0n, nbuf + 1 * UNIT);
+        stage(1, kt + 2);
+        P8_WAIT_VM8(); // U1 of the next tile
+        P8_BARRIER();
+        mfma_quadrant(1, 0, fb0);
+        P8_WAIT_LGKM0();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+        {
+            fb0[j][0] = fb0n[j][0];
+            fb0[j][1] = fb0n[j][1];
+        }
+        P8_BARRIER();
+    }
+    if (wr == 0)
+        P8_BARRIER(); // balance the barrier count of the two groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // clamped tail DMAs must land before the LDS is released
+#undef P8_BARRIER
+#undef P8_WAIT_VM8
+#undef P8_WAIT_VM6
+#undef P8_WAIT_LGKM0
+
+    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
+    const int em = lane & 15, en = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        const size_t row = m0 + wr * 128 + i * 16 + em;
+        const float sr = g.alpha_row[g.per_token ? row : 0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const size_t col = n0 + wc * 64 + j * 16 + en;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = (float) acc[i][j][r] * (g.alpha_col[g.per_channel ? col + r : 0] * sr);
+            const size_t idx = row * g.ldc + col;
+            switch (g.out_type)
+            {
+            case MI355Q_HALF:
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
+                    = make_uint2(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]));
+                break;
+            case MI355Q_BF16:
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
+                    = make_uint2(pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3]));
+                break;
+            case MI355Q_FLOAT:
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+                break;
+            default:
+                *reinterpret_cast<int4*>(reinterpret_cast<int32_t*>(g.C) + idx)
+                    = make_int4((int) rintf(v[0]), (int) rintf(v[1]), (int) rintf(v[2]), (int) rintf(v[3]));
+                break;
+            }
+        }
+    }
+}
+
+void launch_phased(const Gemm8Args& g, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gemm8_phased_kernel, dim3((g.m / 256) * (g.n / 256)), dim3(512), 0, stream, g, g.m / 256,
+        g.n / 256);
+}
+
+// columns [n_begin, n_begin + n_count) of the problem as a problem of its own
+Gemm8Args column_slice(const Gemm8Args& g, int n_begin, int n_count)
+{
+    Gemm8Args s = g;
+    s.B = g.B + (size_t) n_begin * g.k;
+    if (g.per_channel)
+        s.alpha_col = g.alpha_col + n_begin;
+    const size_t esz = (g.out_type == MI355Q_HALF || g.out_type == MI355Q_BF16) ? 2 : 4;
+    s.C = reinterpret_cast<uint8_t*>(g.C) + (size_t) n_begin * esz;
+    s.n = n_count;
+    return s;
+}
+
+// Rounds of the 256 CUs a launch of `blocks` blocks takes, weighted by the tile area and by how well
+// that tile shape runs (measured at 4096 x 13824 x 5120: phased 256^2 = 1.0, 256 x 128 = 0.80, 128^2 = 0.70).
+struct BigTile
+{
+    int tm, tn, blocks_per_cu;
+    float eff;
+};
+constexpr BigTile TILES[3] = {{256, 256, 1, 1.00f}, {256, 128, 1, 0.80f}, {128, 128, 2, 0.70f}};
+
+double tile_cost(const BigTile& t, int m, int n)
+{
+    if (m % t.tm || n % t.tn || n == 0)
+        return 1e30;
+    const double tiles = (double) (m / t.tm) * (n / t.tn);
+    return std::ceil(tiles / (256.0 * t.blocks_per_cu)) * t.blocks_per_cu * t.tm * t.tn / t.eff;
+}
+
+void launch_tile(int c, const Gemm8Args& g, hipStream_t stream)
+{
+    switch (c)
+    {
+    case 0: launch_phased(g, stream); break;
+    case 1: launch_big<256, 128, 4, 2>(g, stream); break;
+    default: launch_big<128, 128, 2, 2>(g, stream); break;
+    }
+}
+
+// Tile-quantisation aware launch: the best single tile shape, or a main column range whose 256 x 256
+// tiles fill whole rounds of the 256 CUs plus a remainder range run with whichever shape fills the
+// chip best (e.g. 4096 x 13824: 864 tiles = 3.375 rounds -> 768 tiles in 3 full rounds + 96 tiles'
+// worth of columns as 192 256 x 128 blocks).
 bool try_launch_big_int8(const Gemm8Args& g, hipStream_t stream)
 {
     if (g.k % 128 != 0 || g.m % 128 != 0 || g.n % 128 != 0)
         return false;
-    const BigTile cand[3] = {{256, 256, 1, 1.00f}, {256, 128, 1, 0.92f}, {128, 128, 2, 0.80f}};
-    int best = -1;
+    const char* force = getenv("MI355Q_GEMM8_TILE"); // measurement override: 0..2 single shape, 3 = old 256^2 kernel
+    if (force && force[0] >= '0' && force[0] <= '2' && tile_cost(TILES[force[0] - '0'], g.m, g.n) < 1e29)
+    {
+        launch_tile(force[0] - '0', g, stream);
+        return true;
+    }
+    if (force && force[0] == '3' && g.m % 256 == 0 && g.n % 256 == 0)
+    {
+        launch_big<256, 256, 2, 4>(g, stream);
+        return true;
+    }
+    int best = -1, best_rem = -1, best_split = 0;
     double best_cost = 1e30;
     for (int c = 0; c < 3; ++c)
     {
-        if (g.m % cand[c].tm || g.n % cand[c].tn)
-            continue;
-        const double tiles = (double) (g.m / cand[c].tm) * (g.n / cand[c].tn);
-        const double rounds = std::ceil(tiles / (256.0 * cand[c].blocks_per_cu));
-        const double cost = rounds * cand[c].blocks_per_cu * cand[c].tm * cand[c].tn / cand[c].eff;
+        const double cost = tile_cost(TILES[c], g.m, g.n);
         if (cost < best_cost)
         {
             best_cost = cost;
             best = c;
+            best_rem = -1;
         }
     }
-    const char* force = getenv("MI355Q_GEMM8_TILE"); // debug / measurement override: 0, 1, 2
-    if (force && force[0] >= '0' && force[0] <= '2' && g.m % cand[force[0] - '0'].tm == 0
-        && g.n % cand[force[0] - '0'].tn == 0)
-        best = force[0] - '0';
-    switch (best)
+    if (g.m % 256 == 0 && g.n >= 512)
     {
-    case 0: launch_big<256, 256, 2, 4>(g, stream); return true;
-    case 1: launch_big<256, 128, 4, 2>(g, stream); return true;
-    case 2: launch_big<128, 128, 2, 2>(g, stream); return true;
-    default: return false;
+        // main range: the largest column count (multiple of 256) whose 256 x 256 tiles are whole rounds
+        const int tiles_m = g.m / 256, tiles_n = g.n / 256;
+        int tn_main = tiles_n;
+        while (tn_main > 0 && (tiles_m * tn_main) % 256 != 0)
+            --tn_main;
+        if (tn_main > 0 && tn_main * 256 < g.n)
+        {
+            const int n_main = tn_main * 256, n_rem = g.n - n_main;
+            for (int c = 0; c < 3; ++c)
+            {
+                // + a fixed charge for the second launch / the pipeline restart (about 1/8 round of a 256^2 tile)
+                const double cost = tile_cost(TILES[0], g.m, n_main) + tile_cost(TILES[c], g.m, n_rem) + 256.0 * 256 / 8;
+                if (cost < best_cost)
+                {
+                    best_cost = cost;
+                    best = 0;
+                    best_rem = c;
+                    best_split = n_main;
+                }
+            }
+        }
     }
+    if (best < 0)
+        return false;
+    if (best_rem < 0)
+        launch_tile(best, g, stream);
+    else
+    {
+        launch_tile(0, column_slice(g, 0, best_split), stream);
+        launch_tile(best_rem, column_slice(g, best_split, g.n - best_split), stream);
+    }
+    return true;
 }
 
 // ---- per-token int8 quantisation: one wave per row (kernels/quantization.cu:93-127)
@@ -547,7 +851,7 @@ void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel,
     if (m == 0)
         return;
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, alphaCol, alphaRow,
-        per_token, per_channel, m, n, k, out_type};
+        per_token, per_channel, m, n, k, out_type, n};
     if (!try_launch_big_int8(g, stream))
     {
         dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
@@ -569,7 +873,7 @@ void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* sc
         return;
     // per-tensor scales: alpha_row = scaleA[0], alpha_col = scaleB[0]
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, scaleB, scaleA, 0, 0, m,
-        n, k, out_type};
+        n, k, out_type, n};
     dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
     hipLaunchKernelGGL((gemm8_kernel<true>), grid, dim3(256), 0, stream, g);
     MQ_HIP(hipGetLastError());

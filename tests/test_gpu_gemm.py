@@ -166,6 +166,14 @@ def test_smooth_quant_gemm_ragged_and_large(cuda):
     _sq_case((0,), 128, 64, True, True, torch.float16, cuda)          # empty batch
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (256, 512, 640), (512, 768, 1024), (768, 1280, 256)])
+def test_smooth_quant_gemm_phased_256_tiles(cuda, m, n, k):
+    # multiples of 256: the phased 256 x 256 kernel, and for n = 1280 with 3 m-tiles no whole round -> single shape;
+    # (512, 768): tiles do not fill a round either; all must be exact, int32 accumulators included
+    _sq_case((m,), n, k, True, True, torch.float16, cuda)
+    _sq_case((m,), n, k, False, False, torch.int32, cuda)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_quantize_per_token(cuda, dtype):
     torch.manual_seed(0)

@@ -1,0 +1,19 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/pmc
+export MI355Q_GEMM8_TILE=${TILE:-0}
+run() { # name, counters...
+  name=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc/$name -- python3 tools/microbench.py gemm8 --m 4096 --n 12288 --k 5120 --steps 4 > gpurun_out/pmc/$name.out 2>&1
+  f=$(find gpurun_out/pmc/$name -name "*counter_collection.csv" | head -1)
+  python3 - "$f" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if "gemm8" in r["Kernel_Name"]:
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in acc.items():
+    print(f"  {k:28s} avg/launch = {sum(v)/len(v):.4g}  (n={len(v)})")
+PY
+}
+run b1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES
+run b2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU SQ_ACTIVE_INST_MISC
+run b3 GRBM_GUI_ACTIVE GRBM_COUNT
