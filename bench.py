@@ -147,6 +147,49 @@ def bench_int8_gemm(dev, steps, m=4096, n=13824, k=5120):
             "frac_of_int8_peak": ops / (dev_s / steps) / 1e12 / INT8_PEAK_TOPS}
 
 
+def bench_fp8_gemm(dev, steps, m=4096, n=14336, k=4096):
+    """cfg5: FP8 e4m3 GEMM, per-tensor scales, Mixtral-8x7B expert shapes (w1/w3 and w2), bf16 out."""
+    from mi355q import functional as F
+    torch.manual_seed(0)
+    a = torch.randn(m, k, device=dev).to(torch.float8_e4m3fn)
+    b = torch.randn(n, k, device=dev).to(torch.float8_e4m3fn)
+    sa = torch.tensor([0.5], device=dev)
+    sb = torch.tensor([0.25], device=dev)
+    _, dev_s = time_steps(lambda: F.fp8_gemm(a, b, sa, sb, "bfloat16"), steps, 2, lambda: None)
+    ops = 2.0 * m * n * k
+    return {"m": m, "n": n, "k": k, "ms_per_call": dev_s / steps * 1e3, "TFLOPS": ops / (dev_s / steps) / 1e12,
+            "frac_of_fp8_peak": ops / (dev_s / steps) / 1e12 / INT8_PEAK_TOPS}
+
+
+def bench_prefill_w4a16(dev, steps, m=4096, n=11008, k=4096, g=128):
+    """a4: prefill-M W4A16 AWQ GEMM (dequant in registers -> bf16 MFMA), Llama-2-7B gate/up shape."""
+    from mi355q import _lib as L
+    import ctypes as C
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    w = torch.randint(-128, 128, (k, n // 2), dtype=torch.int8, device=dev)
+    scale = torch.rand(k // g, n, dtype=dt, device=dev)
+    zero = torch.randn(k // g, n, dtype=dt, device=dev)
+    act = torch.randn(m, k, dtype=dt, device=dev)
+    out = torch.empty(m, n, dtype=dt, device=dev)
+    ws_bytes = L.lib().mi355q_weight_only_gemm_workspace_size(m, n, k, L.WEIGHT_INT4)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    p = L.WeightOnlyParams()
+    p.qweight, p.scales, p.zeros = w.data_ptr(), scale.data_ptr(), zero.data_ptr()
+    p.in_, p.act_scale, p.bias, p.out = act.data_ptr(), None, None, out.data_ptr()
+    p.m, p.n, p.k, p.group_size = m, n, k, g
+    p.weight_type, p.act_type = L.WEIGHT_INT4, L.BF16
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
+
+    def step():
+        rc = L.lib().mi355q_weight_only_gemm(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, L.lib().mi355q_last_error()
+    _, dev_s = time_steps(step, steps, 2, lambda: None)
+    ops = 2.0 * m * n * k
+    return {"m": m, "n": n, "k": k, "ms_per_call": dev_s / steps * 1e3, "TFLOPS": ops / (dev_s / steps) / 1e12,
+            "frac_of_bf16_peak": ops / (dev_s / steps) / 1e12 / 2500.0}
+
+
 def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
     """The oracle (CPU port of the MMHA math) on the same workload shape (`seqs` of the 64 sequences
     x 32 heads x ctx 2048), timed on the host cores torch uses; best of `reps` passes (bounded to a
@@ -241,6 +284,8 @@ def main():
                                      bench_gemv(dev, 48, m=1, n=28672, k=8192, sets=6),
                                      bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6)]
                 sec["int8_gemm"] = [bench_int8_gemm(dev, 10), bench_int8_gemm(dev, 10, n=5120, k=13824)]
+                sec["fp8_gemm"] = [bench_fp8_gemm(dev, 10), bench_fp8_gemm(dev, 10, n=4096, k=14336)]
+                sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)
             res["secondary"] = sec

@@ -10,6 +10,7 @@
 // A is [M, K] row-major, B is [N, K] row-major (smoothQuantGemmPlugin.cpp:224-230), so both MFMA
 // operands are K-contiguous: a lane's fragment is 16 (int8) or 8 (fp8) consecutive bytes of a row.
 #include "kernels.h"
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 
@@ -20,6 +21,7 @@ namespace
 {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) int i32x16_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void gemm8_kernel(Gemm8Args g)
 // v_mfma_i32_16x16x64_i8.  The weight tile is the MFMA A operand and the activation tile the B
 // operand, so a lane ends up with 4 consecutive output columns (n) of one row (m): 8-byte stores.
 // Requires m % TM == 0, n % TN == 0, k % 128 == 0 (other shapes take the 128 x 128 kernel above).
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -384,8 +387,10 @@ void launch_big(const Gemm8Args& g, hipStream_t stream)
 // reads it (RAW); the last read of a slot retires at the latest in the interval after the late
 // group's read (2p+2) and the earliest re-stage is two phases later (intervals 2p+4 / 2p+5) (WAR).
 // Requires m % 256 == 0, n % 256 == 0, k % 128 == 0.
+template <bool FP8>
 __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tiles_m, int tiles_n)
 {
+    typedef typename std::conditional<FP8, f32x4_t, i32x4_t>::type acc_t;
     constexpr int TK = 128;
     constexpr int UNIT = 128 * TK;                                       // 16 KiB
     __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * UNIT]; // [buffer][unit U1..U4]; the ONLY LDS object
@@ -434,16 +439,20 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
     // ---- fragments: lane -> row (l & 15) of a 16-row tile, 16-byte chunk (l >> 4) + 4*ks
     const int frow = lane & 15, fk = lane >> 4;
     const int fsw = (frow >> 1) & 7;
-    const int off_k0 = frow * TK + ((fk ^ fsw) << 4), off_k1 = frow * TK + (((4 + fk) ^ fsw) << 4);
+    // int8: two k-steps of 64 (v_mfma_i32_16x16x64_i8), 16-byte chunks fk and 4 + fk;
+    // fp8: one k-step of 128 (v_mfma_f32_16x16x128_f8f6f4, the double-rate fp8 instruction): the lane's 32
+    // consecutive bytes = chunks 2*fk and 2*fk + 1
+    const int c0 = FP8 ? 2 * fk : fk, c1 = FP8 ? 2 * fk + 1 : 4 + fk;
+    const int off_k0 = frow * TK + ((c0 ^ fsw) << 4), off_k1 = frow * TK + ((c1 ^ fsw) << 4);
     const int a_row0 = wr * 64 * TK; // this wave's rows inside U1 / U4
     const int b_row0 = wc * 32 * TK; // inside U2 / U3
 
-    i32x4_t acc[8][4]; // [m-tile of the wave (2 quadrants x 4)][n-tile (2 quadrants x 2)]
+    acc_t acc[8][4]; // [m-tile of the wave (2 quadrants x 4)][n-tile (2 quadrants x 2)]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[i][j] = i32x4_t{0, 0, 0, 0};
+            acc[i][j] = acc_t{0, 0, 0, 0};
     i32x4_t fa[4][2], fb0[2][2], fb1[2][2], fb0n[2][2]; // activation quadrant, weight quadrants 0 / 1 (+ next tile's 0): [tile][ks]
 
     auto read_a = [&](const uint8_t* unit_base)
@@ -467,14 +476,30 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
     auto mfma_quadrant = [&](int mq, int nq, const i32x4_t (&fb)[2][2])
     {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (FP8)
+        {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[mq * 4 + i][nq * 2 + j]
-                        = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j][ks], fa[i][ks], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
+                {
+                    const i32x8_t w = __builtin_shufflevector(fb[j][0], fb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const i32x8_t x = __builtin_shufflevector(fa[i][0], fa[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[mq * 4 + i][nq * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        w, x, acc[mq * 4 + i][nq * 2 + j], 0, 0, 0, 0, 0, 0);
+                }
+        }
+        else
+        {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mq * 4 + i][nq * 2 + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                            fb[j][ks], fa[i][ks], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 #define P8_BARRIER()                                                                                                   \
@@ -590,9 +615,10 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
     }
 }
 
+template <bool FP8>
 void launch_phased(const Gemm8Args& g, hipStream_t stream)
 {
-    hipLaunchKernelGGL(gemm8_phased_kernel, dim3((g.m / 256) * (g.n / 256)), dim3(512), 0, stream, g, g.m / 256,
+    hipLaunchKernelGGL(gemm8_phased_kernel<FP8>, dim3((g.m / 256) * (g.n / 256)), dim3(512), 0, stream, g, g.m / 256,
         g.n / 256);
 }
 
@@ -630,7 +656,7 @@ void launch_tile(int c, const Gemm8Args& g, hipStream_t stream)
 {
     switch (c)
     {
-    case 0: launch_phased(g, stream); break;
+    case 0: launch_phased<false>(g, stream); break;
     case 1: launch_big<256, 128, 4, 2>(g, stream); break;
     default: launch_big<128, 128, 2, 2>(g, stream); break;
     }
@@ -874,8 +900,13 @@ void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* sc
     // per-tensor scales: alpha_row = scaleA[0], alpha_col = scaleB[0]
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, scaleB, scaleA, 0, 0, m,
         n, k, out_type, n};
-    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm8_kernel<true>), grid, dim3(256), 0, stream, g);
+    if (m % 256 == 0 && n % 256 == 0 && k % 128 == 0 && !getenv("MI355Q_FP8_SMALL_TILE"))
+        launch_phased<true>(g, stream);
+    else
+    {
+        dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
+        hipLaunchKernelGGL((gemm8_kernel<true>), grid, dim3(256), 0, stream, g);
+    }
     MQ_HIP(hipGetLastError());
 }
 

@@ -204,7 +204,7 @@ def test_quantize_e4m3(cuda, mode, dtype):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("m,n,k", [(64, 256, 128), (200, 520, 1008), (512, 1024, 4096)])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 128), (200, 520, 1008), (512, 1024, 4096), (256, 256, 128), (768, 512, 640)])
 def test_fp8_gemm(cuda, out_dtype, m, n, k):
     # parity unpinned by the reference (closed libraries); semantic of quantization/layers.py:777-879
     torch.manual_seed(0)

@@ -42,5 +42,26 @@ for (m, n, k) in [(4096, 13824, 5120), (4096, 5120, 13824), (2048, 4096, 4096)]:
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 10
         print(f"  tile {tile}: {t*1e3:.1f} us  {2.0*m*n*k/t/1e9:.0f} TOPS", flush=True)
+# ---- fp8: phased (16x16x128 f8f6f4) vs the small-tile kernel (16x16x32-class), Mixtral shapes
+for (m, n, k) in [(512, 1024, 4096), (4096, 14336, 4096), (4096, 4096, 14336), (4096, 6144, 4096)]:
+    a = (torch.randn(m, k, device=dev)).to(torch.float8_e4m3fn); b = torch.randn(n, k, device=dev).to(torch.float8_e4m3fn)
+    sa = torch.tensor([0.5], device=dev); sb = torch.tensor([0.25], device=dev)
+    os.environ.pop("MI355Q_FP8_SMALL_TILE", None)
+    o1 = F.fp8_gemm(a, b, sa, sb, "float32"); torch.cuda.synchronize()
+    os.environ["MI355Q_FP8_SMALL_TILE"] = "1"
+    o0 = F.fp8_gemm(a, b, sa, sb, "float32"); torch.cuda.synchronize()
+    err = (o1 - o0).abs().max().item(); scale = o0.abs().max().item()
+    e = err <= 1e-5 * scale * (k ** 0.5); ok &= e
+    print(m, n, k, f"fp8 phased vs small-tile: max err {err:.3e} (max |out| {scale:.1f})", e, flush=True)
+    for small in (True, False):
+        if small: os.environ["MI355Q_FP8_SMALL_TILE"] = "1"
+        else: os.environ.pop("MI355Q_FP8_SMALL_TILE", None)
+        for _ in range(3): F.fp8_gemm(a, b, sa, sb, "bfloat16")
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): F.fp8_gemm(a, b, sa, sb, "bfloat16")
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 10
+        print(f"  {'small-tile' if small else 'phased'}: {t*1e3:.1f} us  {2.0*m*n*k/t/1e9:.0f} TFLOPs", flush=True)
 print("ALL OK" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
