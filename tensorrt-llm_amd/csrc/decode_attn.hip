@@ -14,8 +14,7 @@
 //     (in-wave shuffles, then LDS across waves, then -- for multi-block -- a tiny merge kernel that
 //     keeps partials in fp32).
 //   * the new token's bias + RoPE + cache append (quantised for int8/fp8 caches) is fused in.
-#include "kernels.h"
-#include <cfloat>
+#include "decode_common.h"
 
 namespace mi355q
 {
@@ -23,99 +22,6 @@ namespace mi355q
 namespace
 {
 
-constexpr int NW = 4; // waves per workgroup
-constexpr float NEG_BIG = -1e30f;
-
-struct DecodeArgs
-{
-    const void* qkv;
-    const void* qkv_bias;
-    void* out;
-    const int32_t* seq_lens;
-    const int64_t* block_ptrs;
-    const float* kv_scale_orig_quant;
-    const float* kv_scale_quant_orig;
-    float* part_acc; // [B, Hq, splits, DH]
-    float* part_ml;  // [B, Hq, splits, 2]
-    int batch, num_heads, num_kv_heads;
-    int max_blocks, tpb_log2;
-    int splits;
-    int pos_type, rot_dim, rot_scale_type, rot_max_pos;
-    float rot_base, rot_scale;
-    float score_scale; // 1 / (sqrt(Dh) * q_scaling)
-};
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-
-template <typename T>
-__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c);
-template <>
-__device__ __forceinline__ float dot2<bf16_t>(uint32_t a, uint32_t b, float c)
-{
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
-}
-template <>
-__device__ __forceinline__ float dot2<f16_t>(uint32_t a, uint32_t b, float c)
-{
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
-}
-
-// sum over the LPT lanes that hold one token row; every lane of the group ends with the total.
-template <int LPT>
-__device__ __forceinline__ float group_sum(float v)
-{
-#define MQ_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-    if (LPT >= 2)
-        MQ_DPP_ADD(0xB1); // quad_perm [1,0,3,2]
-    if (LPT >= 4)
-        MQ_DPP_ADD(0x4E); // quad_perm [2,3,0,1]
-    if (LPT >= 8)
-        MQ_DPP_ADD(0x141); // row_half_mirror
-    if (LPT >= 16)
-        MQ_DPP_ADD(0x140); // row_mirror
-#undef MQ_DPP_ADD
-    if (LPT >= 32)
-        v += __shfl_xor(v, 16);
-    if (LPT >= 64)
-        v += __shfl_xor(v, 32);
-    return v;
-}
-
-// KVT: 0 = cache holds T, 1 = int8, 2 = fp8 e4m3 (OCP)
-template <int KVT>
-__device__ __forceinline__ float kv8_to_float(uint32_t w, int byte);
-template <>
-__device__ __forceinline__ float kv8_to_float<1>(uint32_t w, int byte)
-{
-    return (float) (int8_t) (w >> (8 * byte));
-}
-template <>
-__device__ __forceinline__ float kv8_to_float<2>(uint32_t w, int byte)
-{
-    switch (byte)
-    {
-    case 0: return __builtin_amdgcn_cvt_f32_fp8((int) w, 0);
-    case 1: return __builtin_amdgcn_cvt_f32_fp8((int) w, 1);
-    case 2: return __builtin_amdgcn_cvt_f32_fp8((int) w, 2);
-    default: return __builtin_amdgcn_cvt_f32_fp8((int) w, 3);
-    }
-}
-
-__device__ __forceinline__ uint8_t float_to_int8_sat(float x)
-{
-    // cvt.rni.sat.s8.f32 (decoderMaskedMultiheadAttentionUtils.h:3629-3639)
-    float r = rintf(x);
-    r = fminf(fmaxf(r, -128.f), 127.f);
-    return (uint8_t) (int8_t) (int) r;
-}
-
-__device__ __forceinline__ uint8_t float_to_fp8(float x)
-{
-    // OCP e4m3fn, RNE, saturating to +-448 like __nv_fp8_e4m3's default conversion
-    x = fminf(fmaxf(x, -448.f), 448.f);
-    return (uint8_t) (__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
-}
 
 template <typename T, int KVT, int DH, int G, int U>
 __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
@@ -149,52 +55,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     const int tpb = 1 << p.tpb_log2;
     const bool last_split = split == p.splits - 1;
 
-    // ---- stage q (G heads), k, v of the new token: bias add in T, RoPE in fp32, round to T
-    {
-        const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * DH;
-        const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.qkv_bias);
-        for (int i = tid; i < (G + 2) * DH; i += NW * 64)
-        {
-            int vec = i / DH, d = i % DH;
-            int off = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
-            float x = T16<T>::to_float(qkv[off]);
-            if (bias)
-                x = T16<T>::to_float(T16<T>::from_float(x + T16<T>::to_float(bias[off])));
-            smem[i] = x;
-        }
-        __syncthreads();
-        if (p.pos_type == 1 || p.pos_type == 2) // kROPE_GPTJ / kROPE_GPT_NEOX
-        {
-            const int half = p.rot_dim >> 1;
-            float base = p.rot_base, scale = p.rot_scale;
-            // update_rotary_base_n_scale (decoderMaskedMultiheadAttentionUtils.h:2552-2579)
-            if (p.rot_scale_type == 2)
-            {
-                if (tl > p.rot_max_pos)
-                {
-                    float bb = tl * (scale / p.rot_max_pos) - (scale - 1.f);
-                    base = base * powf(bb, (float) p.rot_dim / (float) (p.rot_dim - 2));
-                }
-                scale = 1.f;
-            }
-            else if (p.rot_scale_type == 1)
-                scale = 1.f / scale;
-            for (int i = tid; i < (G + 1) * half; i += NW * 64)
-            {
-                int vec = i / half, j = i % half;
-                float* x = smem + vec * DH;
-                int i0 = p.pos_type == 2 ? j : 2 * j;
-                int i1 = p.pos_type == 2 ? j + half : 2 * j + 1;
-                float ang = ((float) tl * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
-                float sn, cs;
-                sincosf(ang, &sn, &cs);
-                float a = x[i0], c = x[i1];
-                x[i0] = T16<T>::to_float(T16<T>::from_float(cs * a - sn * c));
-                x[i1] = T16<T>::to_float(T16<T>::from_float(cs * c + sn * a));
-            }
-            __syncthreads();
-        }
-    }
+    stage_new_token<T, DH, G>(p, b, hk, tl, smem);
 
     const int ts = lane / LPT;  // token slot inside a wave-load
     const int ch = lane % LPT;  // 16-byte chunk of the row
@@ -565,7 +426,7 @@ void dispatch_g(const mi355q_decode_attention_params& q, const DecodeArgs& a, in
     case 2: dispatch_u<T, KVT, DH, 2>(q, a, u, s); break;
     case 4: dispatch_u<T, KVT, DH, 4>(q, a, u, s); break;
     case 8: dispatch_u<T, KVT, DH, 8>(q, a, u, s); break;
-    default: MQ_UNSUPPORTED("decode attention: q heads per kv head must be 1, 2, 4 or 8 (got %d)", g);
+    default: MQ_UNSUPPORTED("decode attention: q heads per kv head must be 1, 2, 4, 8 (or 16 with head_size 128, tokens_per_block >= 32); got %d", g);
     }
 }
 
@@ -593,9 +454,12 @@ void dispatch_kv(const mi355q_decode_attention_params& q, const DecodeArgs& a, i
         MQ_UNSUPPORTED("decode attention: kv cache type %d", q.kv_type);
 }
 
+#include "decode_attn_gqa.inc"
+
 struct Plan
 {
     int kvb, u, tile, splits;
+    bool gqa;
 };
 
 Plan make_plan(const mi355q_decode_attention_params& q)
@@ -610,6 +474,14 @@ Plan make_plan(const mi355q_decode_attention_params& q)
     Plan pl;
     pl.kvb = q.kv_type == q.act_type ? 2 : 1;
     MQ_CHECK(q.head_size == 64 || q.head_size == 128, "head_size %d not built (64, 128)", q.head_size);
+    pl.gqa = gqa_mfma_applies(q);
+    if (pl.gqa)
+    {
+        pl.u = 1;
+        pl.tile = GQA_STEP;
+        pl.splits = choose_splits(q, pl.tile);
+        return pl;
+    }
     const int tpw = 64 / (q.head_size / (16 / pl.kvb));
     MQ_CHECK(q.tokens_per_block >= tpw, "tokens_per_block %d < %d rows per wave-load", q.tokens_per_block, tpw);
     pl.u = pick_unroll(q.head_size, pl.kvb, q.tokens_per_block, q.num_heads / q.num_kv_heads);
@@ -670,7 +542,14 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
         a.part_acc = reinterpret_cast<float*>(q.workspace);
         a.part_ml = a.part_acc + (size_t) q.batch * q.num_heads * pl.splits * q.head_size;
     }
-    if (q.act_type == MI355Q_BF16)
+    if (pl.gqa)
+    {
+        if (q.act_type == MI355Q_BF16)
+            dispatch_gqa<bf16_t>(q, a, stream);
+        else
+            dispatch_gqa<f16_t>(q, a, stream);
+    }
+    else if (q.act_type == MI355Q_BF16)
         dispatch_kv<bf16_t>(q, a, pl.u, stream);
     else
         dispatch_kv<f16_t>(q, a, pl.u, stream);
