@@ -339,24 +339,39 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
 }
 
 // multi-block merge (reference: decoderMaskedMultiheadAttentionTemplate.h:2634-2786, but partials
-// stay fp32 here).  grid = B*Hq, block = DH.
+// stay fp32 here).  grid = B*Hq, block = DH (64 or 128 threads).
 template <typename T>
 __global__ void decode_attn_merge_kernel(
     const float* part_acc, const float* part_ml, void* out, int splits, int dh)
 {
+    // splits <= 64: the (m, l) pairs are fetched once, in parallel, and the rescale factors shared through LDS
+    __shared__ float c_s[64];
+    __shared__ float ll_s;
     const size_t bh = blockIdx.x;
     const int d = threadIdx.x;
-    float mm = NEG_BIG;
-    for (int s = 0; s < splits; ++s)
-        mm = fmaxf(mm, part_ml[(bh * splits + s) * 2]);
-    float ll = 0.f, o = 0.f;
-    for (int s = 0; s < splits; ++s)
+    if (d < 64)
     {
-        const float c = __builtin_amdgcn_exp2f(part_ml[(bh * splits + s) * 2] - mm);
-        ll += part_ml[(bh * splits + s) * 2 + 1] * c;
-        o += part_acc[(bh * splits + s) * dh + d] * c;
+        const float m = d < splits ? part_ml[(bh * splits + d) * 2] : NEG_BIG;
+        const float l = d < splits ? part_ml[(bh * splits + d) * 2 + 1] : 0.f;
+        float mm = m;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            mm = fmaxf(mm, __shfl_xor(mm, o));
+        const float c = __builtin_amdgcn_exp2f(m - mm);
+        float ll = l * c;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            ll += __shfl_xor(ll, o);
+        c_s[d] = c;
+        if (d == 0)
+            ll_s = ll;
     }
-    reinterpret_cast<uint16_t*>(out)[bh * dh + d] = T16<T>::from_float(o / (ll + 1e-6f));
+    __syncthreads();
+    float o = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < splits; ++s)
+        o += part_acc[(bh * splits + s) * dh + d] * c_s[s];
+    reinterpret_cast<uint16_t*>(out)[bh * dh + d] = T16<T>::from_float(o / (ll_s + 1e-6f));
 }
 
 int ilog2(int x)
@@ -370,7 +385,7 @@ int ilog2(int x)
 int choose_splits(const mi355q_decode_attention_params& q, int tile)
 {
     if (q.multi_block_mode > 0)
-        return q.multi_block_mode;
+        return std::min(q.multi_block_mode, 64); // the merge kernel handles up to 64 partials
     const int wgs = q.batch * q.num_kv_heads;
     const int max_tiles = (q.max_seq_len + tile - 1) / tile;
     // aim for >= 4 workgroups per CU, never less than NW tiles per workgroup
