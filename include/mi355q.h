@@ -249,6 +249,41 @@ extern "C"
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
     mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);
 
+    /* The context (prefill) phase of GPTAttention: plugins/gptAttentionCommon/gptAttentionCommon.cpp:641-1133
+     * enqueueContext = invokeAddFusedQKVBiasTranspose / invokeApplyBiasRopeUpdateKVCache
+     * (kernels/unfusedAttentionKernels.h) + causal attention among the input tokens
+     * (contextFusedMultiHeadAttention/fmhaRunner.h, or the unfused cuBLAS + invokeMaskedSoftmax path :1000-1120)
+     * + the K / V append into the KVBlockArray cache.  One call does all three; a following
+     * mi355q_masked_multihead_attention step with sequence_lengths = context_lengths + 1 continues the sequence. */
+    typedef struct
+    {
+        const void* qkv;            /* remove_padding: [num_tokens, (Hq+2Hkv)*Dh], sequences back to back;
+                                       else [batch, max_context_length, (Hq+2Hkv)*Dh] */
+        const void* qkv_bias;       /* [(Hq+2Hkv)*Dh] or NULL */
+        void* out;                  /* same token indexing, [.., Hq*Dh]; rows past a sequence's length are not written */
+        const int32_t* context_lengths;  /* device [batch] */
+        const int64_t* block_pointers;   /* device [batch, 2, max_blocks_per_seq] or NULL (no cache append) */
+        const float* kv_scale_orig_quant; /* device [1]; needed for an 8-bit cache */
+        void* workspace;            /* mi355q_context_attention_workspace_size bytes */
+        size_t workspace_bytes;
+        int32_t batch, num_heads, num_kv_heads, head_size;
+        int32_t max_blocks_per_seq, tokens_per_block;
+        int32_t max_context_length; /* upper bound of context_lengths (host_context_lengths' max) */
+        int32_t num_tokens;         /* remove_padding: total rows of qkv (sum of context_lengths) */
+        int32_t remove_padding;     /* 0 / 1 */
+        int32_t act_type;           /* MI355Q_HALF / MI355Q_BF16 */
+        int32_t kv_type;            /* act_type, MI355Q_INT8 or MI355Q_FP8 */
+        int32_t position_embedding_type; /* 0 learned-absolute (none applied here), 1 RoPE GPT-J, 2 RoPE GPT-NeoX */
+        int32_t rotary_embedding_dim;
+        float rotary_embedding_base;
+        int32_t rotary_embedding_scale_type;
+        float rotary_embedding_scale;
+        int32_t rotary_embedding_max_positions;
+        float q_scaling;
+    } mi355q_context_attention_params;
+    size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params);
+    mi355q_status mi355q_context_attention(const mi355q_context_attention_params* params, void* stream);
+
     enum
     {
         MI355Q_AR_RING = 0,

@@ -421,3 +421,73 @@ def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_
                 cache.write(b, 0, hk, tl, quantize_kv(torch.from_numpy(k[hk]).to(T), cache.dtype, kv_scale_orig_quant))
                 cache.write(b, 1, hk, tl, quantize_kv(torch.from_numpy(v[hk]).to(T), cache.dtype, kv_scale_orig_quant))
     return out.to(T)
+
+
+# ----------------------------------------------------------------------------- context attention
+def apply_rope_rows(x, positions, rot_dim, kind, base=10000.0, scale=1.0):
+    """apply_rope over rows: x float32 numpy [S, H, Dh], positions int [S] (same pairing / angle rule)."""
+    i = np.arange(0, rot_dim, 2, dtype=np.float32)
+    freq = np.power(np.float32(base), i / np.float32(rot_dim))
+    ang = (positions.astype(np.float32) * np.float32(scale))[:, None] / freq[None, :]  # [S, rot/2]
+    c, s = np.cos(ang).astype(np.float32)[:, None, :], np.sin(ang).astype(np.float32)[:, None, :]
+    y = x.copy()
+    h = rot_dim // 2
+    if kind == "neox":
+        a, b = x[..., :h], x[..., h:rot_dim]
+        y[..., :h] = c * a - s * b
+        y[..., h:rot_dim] = c * b + s * a
+    elif kind == "gptj":
+        a, b = x[..., 0:rot_dim:2], x[..., 1:rot_dim:2]
+        y[..., 0:rot_dim:2] = c * a - s * b
+        y[..., 1:rot_dim:2] = c * b + s * a
+    return y
+
+
+def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_dim, cache=None, q_scaling=1.0,
+                      rope=None, rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None,
+                      kv_scale_orig_quant=1.0):
+    """The context phase of GPTAttention (gptAttentionCommon.cpp:641-1133 enqueueContext), restated:
+      * per input token: bias add in T, RoPE at the token's position in its sequence, rounded to T
+        (invokeApplyBiasRopeUpdateKVCache / invokeAddFusedQKVBiasTranspose, unfusedAttentionKernels.cu);
+      * K / V of every token appended to the paged cache at that position, quantised for an 8-bit cache
+        (same conversion as the generation kernel's, quantize_kv);
+      * causal attention among the input tokens in fp32 over the T-rounded q / k / v -- the reference's
+        unfused path (:1000-1120: cuBLAS QK^T, invokeMaskedSoftmax, cuBLAS PV); the un-quantised K / V are
+        used, as in the reference's context FMHA.  Scale 1/(sqrt(Dh) q_scaling), normaliser sum + 1e-6
+        like the MMHA kernel (the 1e-6 is below T's resolution).
+    qkv_rows: list of torch [len_b, (Hq+2Hkv)*Dh] in T, one per sequence.  Returns a list of [len_b, Hq*Dh] in T.
+    Tolerance parity like decode_attention (the reference rounds P to T before P.V)."""
+    Hq, Hkv, D = num_heads, num_kv_heads, head_dim
+    inv_sqrt = np.float32(1.0 / (math.sqrt(D) * q_scaling))
+    grp = Hq // Hkv
+    outs = []
+    for b, rows in enumerate(qkv_rows):
+        T = rows.dtype
+        S = int(context_lengths[b])
+        assert rows.shape[0] == S
+        x = rows
+        if qkv_bias is not None:
+            x = x + qkv_bias.reshape(1, -1).to(T)
+        x = x.float().numpy().reshape(S, Hq + 2 * Hkv, D).copy()
+        if rope is not None:
+            pos = np.arange(S)
+            x[:, :Hq + Hkv] = apply_rope_rows(x[:, :Hq + Hkv], pos, rot_dim, rope, rope_base, rope_scale)
+            x = torch.from_numpy(x).to(T).float().numpy()
+        q = torch.from_numpy(x[:, :Hq]).double()                 # [S, Hq, D]
+        k = torch.from_numpy(x[:, Hq:Hq + Hkv]).double()         # [S, Hkv, D]
+        v = torch.from_numpy(x[:, Hq + Hkv:]).double()
+        if cache is not None:
+            for hk in range(Hkv):
+                for t in range(S):
+                    cache.write(b, 0, hk, t, quantize_kv(k[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
+                    cache.write(b, 1, hk, t, quantize_kv(v[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
+        out = torch.zeros(S, Hq, D, dtype=torch.float32)
+        mask = torch.tril(torch.ones(S, S, dtype=torch.bool))
+        for h in range(Hq):
+            hk = h // grp
+            logits = (q[:, h] @ k[:, hk].t()).float() * inv_sqrt
+            logits = logits.masked_fill(~mask, float("-inf"))
+            p = torch.exp(logits - logits.max(dim=1, keepdim=True).values)
+            out[:, h] = (p.double() @ v[:, hk]).float() / (p.sum(dim=1, keepdim=True) + 1e-6)
+        outs.append(out.reshape(S, Hq * D).to(T))
+    return outs

@@ -52,4 +52,8 @@ void quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int6
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q);
 void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream);
 
+// context_attn.hip
+size_t context_attention_workspace_size(const mi355q_context_attention_params& q);
+void context_attention(const mi355q_context_attention_params& q, hipStream_t stream);
+
 } // namespace mi355q

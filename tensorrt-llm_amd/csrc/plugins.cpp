@@ -748,69 +748,162 @@ struct GPTAttentionPlugin : PluginBase
         p.multi_block_mode = 0;
         return p;
     }
+    mi355q_context_attention_params contextParams(int batch, int max_blocks, int max_len, int tokens) const
+    {
+        mi355q_context_attention_params p{};
+        p.batch = batch;
+        p.num_heads = f.num_heads;
+        p.num_kv_heads = f.num_kv_heads;
+        p.head_size = f.head_size;
+        p.max_blocks_per_seq = max_blocks;
+        p.tokens_per_block = f.tokens_per_block;
+        p.max_context_length = max_len;
+        p.num_tokens = tokens;
+        p.remove_padding = f.remove_input_padding;
+        p.act_type = f.type;
+        p.kv_type = kvType();
+        p.position_embedding_type = f.position_embedding_type;
+        p.rotary_embedding_dim = f.rotary_embedding_dim;
+        p.rotary_embedding_base = f.rotary_embedding_base;
+        p.rotary_embedding_scale_type = f.rotary_embedding_scale_type;
+        p.rotary_embedding_scale = f.rotary_embedding_scale;
+        p.rotary_embedding_max_positions = f.rotary_embedding_max_positions;
+        p.q_scaling = f.q_scaling;
+        return p;
+    }
     size_t workspaceSize(const mi355q_tensor_desc* in, int, const mi355q_tensor_desc*, int) const override
     {
-        // generation workspace only: multi-block partials (gptAttentionCommon.cpp:1231-1274)
-        if (!f.use_cache || !f.paged_kv_cache)
-            return 0;
+        // max(context, generation) like gptAttentionPlugin.cpp:312-333: the context needs the processed q|k|v
+        // rows (getWorkspaceSizeForContext, gptAttentionCommon.cpp:497-560), the generation the multi-block
+        // partials (:1231-1274)
         const int batch = in[getIdx(CONTEXT_LENGTHS)].dims.d[0];
-        const auto& bp = in[getIdx(KV_CACHE_BLOCK_POINTERS)].dims;
-        const int max_blocks = bp.d[bp.nbDims - 1];
-        mi355q_decode_attention_params p = baseParams(batch, max_blocks, max_blocks * f.tokens_per_block);
-        return mi355q_decode_attention_workspace_size(&p);
+        const auto& qd = in[getIdx(QKV_TENSOR)].dims;
+        const int tokens = f.remove_input_padding ? qd.d[0] : qd.d[0] * qd.d[1];
+        const int max_len = f.remove_input_padding ? std::min<int>(tokens, std::max(f.max_context_length, 1)) : qd.d[1];
+        mi355q_context_attention_params c = contextParams(batch, 0, max_len, tokens);
+        size_t ctx = mi355q_context_attention_workspace_size(&c);
+        size_t gen = 0;
+        if (f.use_cache && f.paged_kv_cache)
+        {
+            const auto& bp = in[getIdx(KV_CACHE_BLOCK_POINTERS)].dims;
+            const int max_blocks = bp.d[bp.nbDims - 1];
+            mi355q_decode_attention_params p = baseParams(batch, max_blocks, max_blocks * f.tokens_per_block);
+            gen = mi355q_decode_attention_workspace_size(&p);
+        }
+        return std::max(ctx, gen);
     }
     void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc* outDesc, const void* const* inputs,
         void* const* outputs, void* workspace, hipStream_t stream) override // :336-393, :396-656
     {
         const int nbSeq = inDesc[getIdx(CONTEXT_LENGTHS)].dims.d[0];
         const int32_t* reqTypes = static_cast<const int32_t*>(inputs[getIdx(REQUEST_TYPES)]);
-        int nbContext = 0;
+        const auto& qkvDims = inDesc[getIdx(QKV_TENSOR)].dims;
+        int nbContext = 0, contextTokenIdxEnd = 0;
         for (int i = 0; i < nbSeq && reqTypes[i] == 0; ++i)
+        {
             ++nbContext;
+            contextTokenIdxEnd += f.remove_input_padding
+                ? static_cast<const int32_t*>(inputs[getIdx(HOST_CONTEXT_LENGTH)])[i]
+                : qkvDims.d[1];
+        }
         for (int i = nbContext; i < nbSeq; ++i)
             MQ_CHECK(reqTypes[i] == 1, "host_request_types: context requests must come first (seq %d)", i);
-        if (nbContext > 0)
-            MQ_UNSUPPORTED(
-                "GPTAttention: the context (prefill) phase is not built in this library (SURVEY 8f 'next'); "
-                "only generation requests can be enqueued");
+        if (nbContext != 0 && nbContext != nbSeq)
+            MQ_CHECK(f.remove_input_padding && f.paged_kv_cache, "mixed requests require remove_input_padding and paged_kv_cache");
         if (nbSeq == 0)
             return;
-        MQ_CHECK(f.use_cache, "KV-cache-less is only supported for context");
-        if (!f.paged_kv_cache)
-            MQ_UNSUPPORTED("GPTAttention: only the paged KV cache (KVBlockArray) is built");
         if (f.cross_attention || f.is_medusa_enabled || f.unfuse_qkv_gemm || f.pos_shift_enabled)
             MQ_UNSUPPORTED("GPTAttention: cross attention / medusa / unfused qkv / pos_shift are not built");
-        const auto& indir = inDesc[getIdx(CACHE_INDIR)].dims;
-        const int beamWidth = indir.d[1];
-        if (beamWidth != 1)
-            MQ_UNSUPPORTED("GPTAttention: beam_width %d (only 1 is built)", beamWidth);
-        const int max_attention_window = indir.d[2];
-        const int cyclic_window = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
-        const int sink = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
-        const int32_t* past = static_cast<const int32_t*>(inputs[getIdx(HOST_PAST_KEY_VALUE_LENGTHS)]);
-        const int max_past = *std::max_element(past, past + nbSeq);
-        if (sink != 0 || cyclic_window < max_past + 1)
-            MQ_UNSUPPORTED("GPTAttention: cyclic / sink-token cache addressing is not built (window %d, sink %d)",
-                cyclic_window, sink);
-        (void) max_attention_window;
-
-        const auto& qkvDims = inDesc[getIdx(QKV_TENSOR)].dims;
+        if (f.use_cache && !f.paged_kv_cache)
+            MQ_UNSUPPORTED("GPTAttention: only the paged KV cache (KVBlockArray) is built");
         const int hidden = qkvDims.d[hiddenDimIndex()];
         MQ_CHECK(hidden == (f.num_heads + 2 * f.num_kv_heads) * f.head_size, "qkv hidden size %d", hidden);
-        const int tokens = f.remove_input_padding ? qkvDims.d[0] : qkvDims.d[0] * qkvDims.d[1];
-        MQ_CHECK(tokens == nbSeq, "Only Medusa mode supports input length > 1 in the generation phase");
-
+        const int outHidden = f.num_heads * f.head_size;
+        const size_t esz = dtype_size(f.type);
+        (void) outDesc;
+        if (nbContext > 0)
+            enqueueContext(0, nbContext, 0, contextTokenIdxEnd, inDesc, inputs, outputs, workspace, stream);
+        if (nbSeq - nbContext > 0)
+        {
+            const int tokens = f.remove_input_padding ? qkvDims.d[0] - contextTokenIdxEnd : qkvDims.d[0] * qkvDims.d[1];
+            enqueueGeneration(nbContext, nbSeq - nbContext, tokens, inDesc,
+                static_cast<const char*>(inputs[getIdx(QKV_TENSOR)]) + (size_t) contextTokenIdxEnd * hidden * esz,
+                static_cast<char*>(outputs[0]) + (size_t) contextTokenIdxEnd * outHidden * esz, inputs, workspace, stream);
+        }
+    }
+    // block table of this layer, first sequence seqBeg (:506-519)
+    const int64_t* blockPointers(const mi355q_tensor_desc* inDesc, const void* const* inputs, int seqBeg, int& max_blocks) const
+    {
         const auto& bpDims = inDesc[getIdx(KV_CACHE_BLOCK_POINTERS)].dims; // [layers, B, 2, max_blocks]
-        const int max_blocks = bpDims.d[bpDims.nbDims - 1];
+        max_blocks = bpDims.d[bpDims.nbDims - 1];
         const int64_t seqStride = dims_prod(bpDims, 2, bpDims.nbDims);
-        const int64_t layerOffset = (int64_t) f.layer_idx * bpDims.d[1] * seqStride; // :506-519
-
-        mi355q_decode_attention_params p = baseParams(nbSeq, max_blocks, max_past + 1);
-        p.qkv = inputs[getIdx(QKV_TENSOR)];
+        const int64_t layerOffset = (int64_t) f.layer_idx * bpDims.d[1] * seqStride;
+        return static_cast<const int64_t*>(inputs[getIdx(KV_CACHE_BLOCK_POINTERS)]) + layerOffset + seqBeg * seqStride;
+    }
+    void checkWindow(const mi355q_tensor_desc* inDesc, const void* const* inputs, int need) const
+    {
+        const auto& indir = inDesc[getIdx(CACHE_INDIR)].dims;
+        if (indir.d[1] != 1)
+            MQ_UNSUPPORTED("GPTAttention: beam_width %d (only 1 is built)", (int) indir.d[1]);
+        const int cyclic_window = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
+        const int sink = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
+        if (sink != 0 || cyclic_window < need)
+            MQ_UNSUPPORTED("GPTAttention: cyclic / sink-token cache addressing is not built (window %d, sink %d, kv length %d)",
+                cyclic_window, sink, need);
+    }
+    void enqueueContext(int seqBeg, int nb, int tokenBeg, int nbTokens, const mi355q_tensor_desc* inDesc,
+        const void* const* inputs, void* const* outputs, void* workspace, hipStream_t stream) // enqueueSome is_context, :565-600
+    {
+        MQ_CHECK(seqBeg == 0 && tokenBeg == 0, "context requests come first");
+        if (f.mask_type != 1)
+            MQ_UNSUPPORTED("GPTAttention context: only the causal mask (AttentionMaskType::CAUSAL = 1) is built, got %d", f.mask_type);
+        if (f.position_embedding_type != 0 && f.position_embedding_type != 1 && f.position_embedding_type != 2)
+            MQ_UNSUPPORTED("GPTAttention context: position_embedding_type %d is not built (0, 1, 2)", f.position_embedding_type);
+        const auto& qkvDims = inDesc[getIdx(QKV_TENSOR)].dims;
+        int max_len;
+        if (f.remove_input_padding)
+        {
+            const int32_t* hl = static_cast<const int32_t*>(inputs[getIdx(HOST_CONTEXT_LENGTH)]);
+            max_len = *std::max_element(hl, hl + nb);
+        }
+        else
+            max_len = qkvDims.d[1];
+        if (f.max_context_length > 0)
+            MQ_CHECK(max_len <= f.max_context_length, "max_context_q_len %d > max_context_length %d", max_len, f.max_context_length);
+        int max_blocks = 0;
+        mi355q_context_attention_params c = contextParams(nb, 0, max_len, nbTokens);
+        if (f.use_cache)
+        {
+            checkWindow(inDesc, inputs, max_len);
+            c.block_pointers = blockPointers(inDesc, inputs, seqBeg, max_blocks);
+            c.max_blocks_per_seq = max_blocks;
+            if (hasKvQuant())
+                c.kv_scale_orig_quant = static_cast<const float*>(inputs[getIdx(KV_CACHE_QUANTIZATION_SCALE)]);
+        }
+        c.qkv = inputs[getIdx(QKV_TENSOR)];
+        c.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
+        c.out = outputs[0];
+        c.context_lengths = static_cast<const int32_t*>(inputs[getIdx(CONTEXT_LENGTHS)]) + seqBeg;
+        c.workspace = workspace;
+        c.workspace_bytes = workspace ? mi355q_context_attention_workspace_size(&c) : 0;
+        context_attention(c, stream);
+    }
+    void enqueueGeneration(int seqBeg, int nb, int tokens, const mi355q_tensor_desc* inDesc, const void* qkv, void* out,
+        const void* const* inputs, void* workspace, hipStream_t stream) // enqueueSome !is_context, :606-656
+    {
+        MQ_CHECK(f.use_cache, "KV-cache-less is only supported for context");
+        MQ_CHECK(tokens == nb, "Only Medusa mode supports input length > 1 in the generation phase");
+        const int32_t* past = static_cast<const int32_t*>(inputs[getIdx(HOST_PAST_KEY_VALUE_LENGTHS)]) + seqBeg;
+        const int max_past = *std::max_element(past, past + nb);
+        checkWindow(inDesc, inputs, max_past + 1);
+        int max_blocks = 0;
+        const int64_t* bp = blockPointers(inDesc, inputs, seqBeg, max_blocks);
+        mi355q_decode_attention_params p = baseParams(nb, max_blocks, max_past + 1);
+        p.qkv = qkv;
         p.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
-        p.out = outputs[0];
-        p.sequence_lengths = static_cast<const int32_t*>(inputs[getIdx(SEQUENCE_LENGTH)]);
-        p.block_pointers = static_cast<const int64_t*>(inputs[getIdx(KV_CACHE_BLOCK_POINTERS)]) + layerOffset;
+        p.out = out;
+        p.sequence_lengths = static_cast<const int32_t*>(inputs[getIdx(SEQUENCE_LENGTH)]) + seqBeg;
+        p.block_pointers = bp;
         if (hasKvQuant())
         {
             p.kv_scale_orig_quant = static_cast<const float*>(inputs[getIdx(KV_CACHE_QUANTIZATION_SCALE)]);
@@ -818,7 +911,6 @@ struct GPTAttentionPlugin : PluginBase
         }
         p.workspace = workspace;
         p.workspace_bytes = workspace ? mi355q_decode_attention_workspace_size(&p) : 0;
-        (void) outDesc;
         masked_multihead_attention(p, stream);
     }
     size_t serializationSize() const override
@@ -1272,6 +1364,28 @@ extern "C"
             {
                 MQ_CHECK(params, "null argument");
                 masked_multihead_attention(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params)
+    {
+        size_t res = 0;
+        guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                res = context_attention_workspace_size(*params);
+            });
+        return res;
+    }
+
+    mi355q_status mi355q_context_attention(const mi355q_context_attention_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                context_attention(*params, static_cast<hipStream_t>(stream));
             });
     }
 

@@ -79,6 +79,23 @@ class DecodeAttentionParams(C.Structure):
     ]
 
 
+class ContextAttentionParams(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("qkv_bias", C.c_void_p), ("out", C.c_void_p),
+        ("context_lengths", C.c_void_p), ("block_pointers", C.c_void_p),
+        ("kv_scale_orig_quant", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("batch", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32), ("head_size", C.c_int32),
+        ("max_blocks_per_seq", C.c_int32), ("tokens_per_block", C.c_int32), ("max_context_length", C.c_int32),
+        ("num_tokens", C.c_int32), ("remove_padding", C.c_int32),
+        ("act_type", C.c_int32), ("kv_type", C.c_int32),
+        ("position_embedding_type", C.c_int32), ("rotary_embedding_dim", C.c_int32),
+        ("rotary_embedding_base", C.c_float), ("rotary_embedding_scale_type", C.c_int32),
+        ("rotary_embedding_scale", C.c_float), ("rotary_embedding_max_positions", C.c_int32),
+        ("q_scaling", C.c_float),
+    ]
+
+
 class Mi355qError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"mi355q status {status}: {msg}")
@@ -123,6 +140,8 @@ SYMBOLS = {
     "mi355q_quantize_e4m3": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_decode_attention_workspace_size": (_sz, [C.POINTER(DecodeAttentionParams)]),
     "mi355q_masked_multihead_attention": (_i32, [C.POINTER(DecodeAttentionParams), _vp]),
+    "mi355q_context_attention_workspace_size": (_sz, [C.POINTER(ContextAttentionParams)]),
+    "mi355q_context_attention": (_i32, [C.POINTER(ContextAttentionParams), _vp]),
     "mi355q_allreduce_select_implementation": (_i32, [_sz, _i32, _sz]),
 }
 

@@ -189,10 +189,11 @@ def test_attention_plugin_entry_indexing_and_errors():
     assert plg.get_output_dimensions(0, shapes) == [B, 1, 8 * 64]
     blob = plg.serialize()
     assert Plugin.deserialize("GPTAttention", blob).serialize() == blob
-    # a context request is refused with a clear message (no silent fallback), host-only check
+    # context + generation requests in one padded batch are refused like gptAttentionPlugin.cpp:363-367
+    # (host-only check: fails before anything is launched)
     qkv = torch.zeros(B, 1, 12 * 64, dtype=torch.float16)
     i32 = lambda *v: torch.tensor(v, dtype=torch.int32)
-    with pytest.raises(L.Mi355qError, match="context"):
+    with pytest.raises(L.Mi355qError, match="mixed requests require remove_input_padding"):
         plg.enqueue([qkv, i32(5, 5, 5), i32(4, 4, 4), i32(64), i32(0), i32(5, 5, 5),
                      torch.zeros(B, 1, 64, dtype=torch.int32), i32(0, 1, 1),
                      torch.zeros(1, B, 2, 4, dtype=torch.int64), torch.zeros(1, B, 2, 4, dtype=torch.int64),
