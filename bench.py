@@ -190,6 +190,47 @@ def bench_prefill_w4a16(dev, steps, m=4096, n=11008, k=4096, g=128):
             "frac_of_bf16_peak": ops / (dev_s / steps) / 1e12 / 2500.0}
 
 
+def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16"):
+    """8f rank 1: context (prefill) attention, Llama-2-7B heads: bias-less RoPE + paged KV append + causal
+    attention; flops counted on the causal half (2 * 2 * S^2/2 * D per head)."""
+    from mi355q import _lib as L
+    import ctypes as C
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    qkv = (torch.randn(B, S, (H + 2 * Hkv) * D, device=dev) * 0.5).to(dt)
+    out = torch.empty(B, S, H * D, dtype=dt, device=dev)
+    cl = torch.full((B,), S, dtype=torch.int32, device=dev)
+    kvdt = {"bf16": dt, "int8": torch.int8, "fp8": torch.float8_e4m3fn}[kv]
+    nblk = B * (S // tpb)
+    pool = torch.zeros(nblk, 2, Hkv, tpb, D, dtype=kvdt, device=dev)
+    be = Hkv * tpb * D * pool.element_size()
+    ids = torch.randperm(nblk).reshape(B, S // tpb)
+    ptrs = (torch.stack([ids * 2 * be, ids * 2 * be + be], 1) + pool.data_ptr()).to(torch.int64).to(dev)
+    sc = torch.tensor([8.0], device=dev)
+    p = L.ContextAttentionParams()
+    p.qkv, p.out, p.context_lengths, p.block_pointers = qkv.data_ptr(), out.data_ptr(), cl.data_ptr(), ptrs.data_ptr()
+    p.kv_scale_orig_quant = sc.data_ptr()
+    p.batch, p.num_heads, p.num_kv_heads, p.head_size = B, H, Hkv, D
+    p.max_blocks_per_seq, p.tokens_per_block = S // tpb, tpb
+    p.max_context_length, p.num_tokens, p.remove_padding = S, B * S, 0
+    p.act_type = L.BF16
+    p.kv_type = {"bf16": L.BF16, "int8": L.INT8, "fp8": L.FP8}[kv]
+    p.position_embedding_type, p.rotary_embedding_dim, p.rotary_embedding_base = 2, D, 10000.0
+    p.rotary_embedding_scale, p.rotary_embedding_max_positions, p.q_scaling = 1.0, 4096, 1.0
+    need = L.lib().mi355q_context_attention_workspace_size(C.byref(p))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    p.workspace, p.workspace_bytes = ws.data_ptr(), need
+
+    def step():
+        rc = L.lib().mi355q_context_attention(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, L.lib().mi355q_last_error()
+    _, dev_s = time_steps(step, steps, 2, lambda: None)
+    flops = 4.0 * B * H * D * (S * (S + 1) / 2)
+    return {"batch": B, "heads": H, "kv_heads": Hkv, "head_dim": D, "seq": S, "kv_cache": kv,
+            "ms_per_call": dev_s / steps * 1e3, "TFLOPS_causal": flops / (dev_s / steps) / 1e12,
+            "frac_of_bf16_peak": flops / (dev_s / steps) / 1e12 / 2500.0}
+
+
 def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
     """The oracle (CPU port of the MMHA math) on the same workload shape (`seqs` of the 64 sequences
     x 32 heads x ctx 2048), timed on the host cores torch uses; best of `reps` passes (bounded to a
@@ -285,6 +326,8 @@ def main():
                                      bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6)]
                 sec["int8_gemm"] = [bench_int8_gemm(dev, 10), bench_int8_gemm(dev, 10, n=5120, k=13824)]
                 sec["fp8_gemm"] = [bench_fp8_gemm(dev, 10), bench_fp8_gemm(dev, 10, n=4096, k=14336)]
+                sec["context_attention"] = [bench_context_attention(dev, 10),
+                                            bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8")]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)

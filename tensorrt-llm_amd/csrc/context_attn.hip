@@ -1,16 +1,18 @@
 // context_attn.hip -- the context (prefill) phase of GPTAttention over the paged cache:
 //   1. ctx_prepare_kernel: bias + RoPE on q, k of every input token, K / V appended to the KVBlockArray
-//      cache (quantised for int8 / fp8 caches), processed q | k | v rows written to the workspace.
+//      cache (quantised for int8 / fp8 caches), processed q, k, v written HEAD-MAJOR to the workspace
+//      ([head][token row][Dh]: a head's rows are contiguous, which is what the attention kernel streams).
 //      Replaces invokeAddFusedQKVBiasTranspose / invokeApplyBiasRopeUpdateKVCache
 //      (kernels/unfusedAttentionKernels.cu; called from gptAttentionCommon.cpp:930-990).
 //   2. ctx_attn_kernel: causal flash attention among the input tokens of each sequence (the reference's
 //      context FMHA, gptAttentionCommon.cpp:1000-1075 -> contextFusedMultiHeadAttention/fmhaRunner.cpp; cubins
 //      only, behaviour spec = unfused softmax(QK^T / sqrt(d)) V with the causal mask), on MFMA:
-//        S^T = K . Q^T per 32-token step (K rows straight to A-fragment layout), online softmax per query
-//        column in the log2 domain, the probability registers are the B fragment of O^T += V^T . P^T,
-//        V through a per-wave swizzled LDS tile read back transposed (ds_read_b64_tr_b16) -- the decode GQA
-//        kernel's structure with the 16 "columns" being query rows instead of query heads.
-//      workgroup = (128-row query tile, q head, sequence), 4 waves x 32 query rows.
+//        workgroup = (128-row query tile, q head, sequence), 4 waves x 32 query rows, 2 workgroups per CU;
+//        K / V tiles of 64 keys stream through a 2-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4,
+//        swizzle applied on the source address), shared by the 4 waves; one barrier per tile;
+//        S^T = K . Q^T (K fragments by ds_read_b128, Q^T fragments resident in registers), online softmax per
+//        query column in the log2 domain, the probability registers ARE the B fragment of O^T += V^T . P^T,
+//        V^T fragments by the transposing LDS read (ds_read_b64_tr_b16) from the row-major V tile.
 // Scope: causal mask, fp16 / bf16, head size 64 / 128, MHA / GQA / MQA, padded or packed input, paged cache;
 // the attention uses the un-quantised K / V of the input tokens (as the reference's context FMHA does).
 #include "decode_common.h"
@@ -26,18 +28,38 @@ typedef __attribute__((ext_vector_type(8))) _Float16 cf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float cf32x4_t;
 typedef __attribute__((ext_vector_type(4))) short cs16x4_t;
 typedef __attribute__((address_space(3))) cs16x4_t lds_cs16x4_t;
+typedef __attribute__((address_space(3))) void ctx_lds_void_t;
+typedef __attribute__((address_space(1))) const void ctx_gbl_void_t;
+
+// LDS-DMA issued from inline asm: the compiler's waitcnt pass makes every LDS read that follows a
+// __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot tell the ring stages apart), which would serialise
+// the prefetch with the compute.  Issued this way the DMA is ordered only by the explicit s_waitcnt vmcnt + barrier
+// of the tile loop.  lds_off: wave-uniform LDS byte address; lane l's 16 bytes land at lds_off + 16 l.
+__device__ __forceinline__ void ctx_dma16(const void* gptr, uint32_t lds_off)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_off) : "memory", "m0");
+}
+
+// fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max_f32 per operand first; the scores are never sNaN
+__device__ __forceinline__ float ctx_max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 struct CtxArgs
 {
     const uint16_t* qkv;      // input rows [(Hq + 2 Hkv) * Dh]
     const uint16_t* qkv_bias; // or null
-    uint16_t* proc;           // workspace: processed rows, same indexing as qkv
-    uint16_t* out;            // [tokens, Hq * Dh]
+    uint16_t* proc;           // workspace: q [Hq][rows][Dh] | k [Hkv][rows][Dh] | v [Hkv][rows][Dh]
+    uint16_t* out;            // [rows, Hq * Dh]
     const int32_t* ctx_lens;  // device [B]
     const int32_t* offsets;   // device [B]: first token row of each sequence (packed input) or null (padded: b * S)
     const int64_t* block_ptrs;
     const float* kv_scale_orig_quant;
     int batch, max_len, num_heads, num_kv_heads, head_size;
+    int rows;                 // total token rows of qkv (padded: B * S)
     int max_blocks, tpb_log2, kv_type; // 0 = T, 1 = int8, 2 = fp8
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale, score_scale;
@@ -68,8 +90,8 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
     const int hidden = (Hq + 2 * Hkv) * D;
     const size_t row = (size_t) (p.offsets ? p.offsets[b] : b * p.max_len) + s;
     const uint16_t* src = p.qkv + row * hidden;
-    uint16_t* dst = p.proc + row * hidden;
-    extern __shared__ float xs[]; // [hidden] floats already rounded to T
+    extern __shared__ float xs[]; // [hidden] floats already rounded to T, then [rot_dim] cos | sin
+    float* cs_tab = xs + hidden;
     for (int i = threadIdx.x; i < hidden; i += 256)
     {
         float x = T16<T>::to_float(src[i]);
@@ -77,10 +99,11 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
             x = T16<T>::to_float(T16<T>::from_float(x + T16<T>::to_float(p.qkv_bias[i]))); // add in T
         xs[i] = x;
     }
-    __syncthreads();
-    if (p.pos_type == 1 || p.pos_type == 2) // kROPE_GPTJ / kROPE_GPT_NEOX on q and k heads, position s
+    const bool rope = p.pos_type == 1 || p.pos_type == 2; // kROPE_GPTJ / kROPE_GPT_NEOX on q and k heads, position s
+    const int half = p.rot_dim >> 1;
+    if (rope && (int) threadIdx.x < half) // the angles only depend on (position, pair index): one table per token
     {
-        const int half = p.rot_dim >> 1;
+        const int j = threadIdx.x;
         float base = p.rot_base, scale = p.rot_scale;
         if (p.rot_scale_type == 2) // dynamic NTK (decoderMaskedMultiheadAttentionUtils.h:2552-2579) at the sequence length
         {
@@ -93,23 +116,34 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         }
         else if (p.rot_scale_type == 1)
             scale = 1.f / scale;
+        const float ang = ((float) s * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        cs_tab[2 * j] = cs;
+        cs_tab[2 * j + 1] = sn;
+    }
+    __syncthreads();
+    if (rope)
+    {
         for (int i = threadIdx.x; i < (Hq + Hkv) * half; i += 256)
         {
             const int vec = i / half, j = i % half;
             float* x = xs + vec * D;
             const int i0 = p.pos_type == 2 ? j : 2 * j;
             const int i1 = p.pos_type == 2 ? j + half : 2 * j + 1;
-            const float ang = ((float) s * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
-            float sn, cs;
-            sincosf(ang, &sn, &cs);
+            const float cs = cs_tab[2 * j], sn = cs_tab[2 * j + 1];
             const float a = x[i0], c = x[i1];
             x[i0] = T16<T>::to_float(T16<T>::from_float(cs * a - sn * c));
             x[i1] = T16<T>::to_float(T16<T>::from_float(cs * c + sn * a));
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < hidden; i += 256)
-        dst[i] = T16<T>::from_float(xs[i]);
+    // processed rows, head-major: vector v of the row goes to proc[(v' * rows + row) * D] with q heads first
+    for (int i = threadIdx.x; i < hidden / 2; i += 256)
+    {
+        const int e = 2 * i, vec = e / D, d = e % D;
+        *reinterpret_cast<uint32_t*>(p.proc + ((size_t) vec * p.rows + row) * D + d) = pack2<T>(xs[e], xs[e + 1]);
+    }
     // cache append at position s: block [Hkv][tokens_per_block][Dh]
     if (p.block_ptrs)
     {
@@ -117,18 +151,173 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         const int64_t* bp = p.block_ptrs + (size_t) b * 2 * p.max_blocks;
         const int blk = s >> p.tpb_log2, tin = s & (tpb - 1);
         const float qs = p.kv_type ? p.kv_scale_orig_quant[0] : 1.f;
-        for (int i = threadIdx.x; i < 2 * Hkv * D; i += 256)
+        for (int i = threadIdx.x; i < 2 * Hkv * D / 4; i += 256) // 4 consecutive d per thread
         {
-            const int kv = i / (Hkv * D), rem = i % (Hkv * D), hk = rem / D, d = rem % D;
-            const float x = xs[(Hq + kv * Hkv + hk) * D + d];
+            const int e4 = 4 * i;
+            const int kv = e4 / (Hkv * D), rem = e4 % (Hkv * D), hk = rem / D, d = rem % D;
+            const float* x = xs + (Hq + kv * Hkv + hk) * D + d;
             const size_t e = ((size_t) hk * tpb + tin) * D + d;
             char* base = reinterpret_cast<char*>(bp[kv * p.max_blocks + blk]);
             if (p.kv_type == 0)
-                reinterpret_cast<uint16_t*>(base)[e] = T16<T>::from_float(x);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + e) = make_uint2(pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]));
             else if (p.kv_type == 1)
-                reinterpret_cast<uint8_t*>(base)[e] = float_to_int8_sat(x * qs);
+                *reinterpret_cast<uint32_t*>(base + e) = (uint32_t) float_to_int8_sat(x[0] * qs) | ((uint32_t) float_to_int8_sat(x[1] * qs) << 8)
+                    | ((uint32_t) float_to_int8_sat(x[2] * qs) << 16) | ((uint32_t) float_to_int8_sat(x[3] * qs) << 24);
             else
-                reinterpret_cast<uint8_t*>(base)[e] = float_to_fp8(x * qs);
+                *reinterpret_cast<uint32_t*>(base + e) = (uint32_t) float_to_fp8(x[0] * qs) | ((uint32_t) float_to_fp8(x[1] * qs) << 8)
+                    | ((uint32_t) float_to_fp8(x[2] * qs) << 16) | ((uint32_t) float_to_fp8(x[3] * qs) << 24);
+        }
+    }
+}
+
+// Fast form of the prepare kernel for the common layouts (no RoPE, GPT-J pairs, or GPT-NeoX with
+// rotary_embedding_dim == head_size): 16-byte loads / stores, no LDS staging of the row.  A work item is one head
+// vector's chunk pair (c, c + Dh/16): the two 16-byte chunks that NeoX rotates against each other.  Same arithmetic,
+// in the same order, as ctx_prepare_kernel (bias add in T, rotation in fp32, one rounding to T).
+// grid (max_len, B), block 256.
+template <typename T>
+__global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
+{
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int len = p.ctx_lens[b];
+    if (s >= len)
+        return;
+    const int Hq = p.num_heads, Hkv = p.num_kv_heads, D = p.head_size;
+    const int nvec = Hq + 2 * Hkv, hidden = nvec * D;
+    const size_t row = (size_t) (p.offsets ? p.offsets[b] : b * p.max_len) + s;
+    const uint16_t* src = p.qkv + row * hidden;
+    __shared__ float cs_tab[128]; // [j] cos | [64 + j] sin, j < rot_dim / 2 <= 64
+    const bool rope = p.pos_type == 1 || p.pos_type == 2;
+    const int half = p.rot_dim >> 1;
+    if (rope)
+    {
+        if ((int) threadIdx.x < half)
+        {
+            const int j = threadIdx.x;
+            float base = p.rot_base, scale = p.rot_scale;
+            if (p.rot_scale_type == 2)
+            {
+                if (len > p.rot_max_pos)
+                {
+                    const float bb = len * (scale / p.rot_max_pos) - (scale - 1.f);
+                    base = base * powf(bb, (float) p.rot_dim / (float) (p.rot_dim - 2));
+                }
+                scale = 1.f;
+            }
+            else if (p.rot_scale_type == 1)
+                scale = 1.f / scale;
+            const float ang = ((float) s * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            cs_tab[j] = cs;
+            cs_tab[64 + j] = sn;
+        }
+        __syncthreads();
+    }
+    const int cpv = D / 16; // chunk pairs per vector: 8 / 4
+    const int tpb = 1 << p.tpb_log2;
+    const int blk = s >> p.tpb_log2, tin = s & (tpb - 1);
+    const int64_t* bp = p.block_ptrs ? p.block_ptrs + (size_t) b * 2 * p.max_blocks : nullptr;
+    const float qs = (p.block_ptrs && p.kv_type) ? p.kv_scale_orig_quant[0] : 1.f;
+    for (int it = threadIdx.x; it < nvec * cpv; it += 256)
+    {
+        const int vec = it / cpv, c = it % cpv;
+        const int d0 = 8 * c, d1 = 8 * c + D / 2;
+        const uint4 r0 = *reinterpret_cast<const uint4*>(src + vec * D + d0);
+        const uint4 r1 = *reinterpret_cast<const uint4*>(src + vec * D + d1);
+        const uint32_t w0[4] = {r0.x, r0.y, r0.z, r0.w}, w1[4] = {r1.x, r1.y, r1.z, r1.w};
+        float x0[8], x1[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            x0[2 * i] = T16<T>::lo(w0[i]);
+            x0[2 * i + 1] = T16<T>::hi(w0[i]);
+            x1[2 * i] = T16<T>::lo(w1[i]);
+            x1[2 * i + 1] = T16<T>::hi(w1[i]);
+        }
+        if (p.qkv_bias)
+        {
+            const uint4 b0 = *reinterpret_cast<const uint4*>(p.qkv_bias + vec * D + d0);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(p.qkv_bias + vec * D + d1);
+            const uint32_t v0[4] = {b0.x, b0.y, b0.z, b0.w}, v1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                x0[2 * i] = T16<T>::to_float(T16<T>::from_float(x0[2 * i] + T16<T>::lo(v0[i])));
+                x0[2 * i + 1] = T16<T>::to_float(T16<T>::from_float(x0[2 * i + 1] + T16<T>::hi(v0[i])));
+                x1[2 * i] = T16<T>::to_float(T16<T>::from_float(x1[2 * i] + T16<T>::lo(v1[i])));
+                x1[2 * i + 1] = T16<T>::to_float(T16<T>::from_float(x1[2 * i + 1] + T16<T>::hi(v1[i])));
+            }
+        }
+        if (rope && vec < Hq + Hkv)
+        {
+            if (p.pos_type == 2) // NeoX, rot_dim == D: element d0 + i pairs with d1 + i, angle index d0 + i
+            {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                {
+                    const float cs = cs_tab[d0 + i], sn = cs_tab[64 + d0 + i];
+                    const float a = x0[i], c2 = x1[i];
+                    x0[i] = cs * a - sn * c2;
+                    x1[i] = cs * c2 + sn * a;
+                }
+            }
+            else // GPT-J: pairs (2j, 2j+1) inside a chunk, elements >= rot_dim pass through
+            {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    const int j0 = (d0 >> 1) + i, j1 = (d1 >> 1) + i;
+                    if (j0 < half)
+                    {
+                        const float cs = cs_tab[j0], sn = cs_tab[64 + j0];
+                        const float a = x0[2 * i], c2 = x0[2 * i + 1];
+                        x0[2 * i] = cs * a - sn * c2;
+                        x0[2 * i + 1] = cs * c2 + sn * a;
+                    }
+                    if (j1 < half)
+                    {
+                        const float cs = cs_tab[j1], sn = cs_tab[64 + j1];
+                        const float a = x1[2 * i], c2 = x1[2 * i + 1];
+                        x1[2 * i] = cs * a - sn * c2;
+                        x1[2 * i + 1] = cs * c2 + sn * a;
+                    }
+                }
+            }
+        }
+        const uint4 o0 = make_uint4(pack2<T>(x0[0], x0[1]), pack2<T>(x0[2], x0[3]), pack2<T>(x0[4], x0[5]), pack2<T>(x0[6], x0[7]));
+        const uint4 o1 = make_uint4(pack2<T>(x1[0], x1[1]), pack2<T>(x1[2], x1[3]), pack2<T>(x1[4], x1[5]), pack2<T>(x1[6], x1[7]));
+        uint16_t* dst = p.proc + ((size_t) vec * p.rows + row) * D;
+        *reinterpret_cast<uint4*>(dst + d0) = o0;
+        *reinterpret_cast<uint4*>(dst + d1) = o1;
+        if (bp && vec >= Hq)
+        {
+            const int kv = (vec - Hq) / Hkv, hk = (vec - Hq) % Hkv;
+            const size_t e = ((size_t) hk * tpb + tin) * D;
+            char* base = reinterpret_cast<char*>(bp[kv * p.max_blocks + blk]);
+            if (p.kv_type == 0)
+            {
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + e + d0) = o0;
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + e + d1) = o1;
+            }
+            else
+            {
+                // quantise the T-rounded values, like the generic kernel
+                const uint32_t q0[4] = {o0.x, o0.y, o0.z, o0.w}, q1[4] = {o1.x, o1.y, o1.z, o1.w};
+                uint32_t c0[2] = {0, 0}, c1[2] = {0, 0};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                {
+                    const float a = (i & 1) ? T16<T>::hi(q0[i >> 1]) : T16<T>::lo(q0[i >> 1]);
+                    const float c2 = (i & 1) ? T16<T>::hi(q1[i >> 1]) : T16<T>::lo(q1[i >> 1]);
+                    const uint32_t ca = p.kv_type == 1 ? float_to_int8_sat(a * qs) : float_to_fp8(a * qs);
+                    const uint32_t cb = p.kv_type == 1 ? float_to_int8_sat(c2 * qs) : float_to_fp8(c2 * qs);
+                    c0[i >> 2] |= ca << (8 * (i & 3));
+                    c1[i >> 2] |= cb << (8 * (i & 3));
+                }
+                *reinterpret_cast<uint2*>(base + e + d0) = make_uint2(c0[0], c0[1]);
+                *reinterpret_cast<uint2*>(base + e + d1) = make_uint2(c1[0], c1[1]);
+            }
         }
     }
 }
@@ -146,19 +335,25 @@ __device__ __forceinline__ cf32x4_t ctx_mfma<f16_t>(const uint4& a, const uint4&
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cf16x8_t, a), __builtin_bit_cast(cf16x8_t, b), c, 0, 0, 0);
 }
 
-constexpr int CTX_STEP = 32; // key tokens per step
+constexpr int CTX_KT = 64;   // keys per tile
 constexpr int CTX_QW = 32;   // query rows per wave
 constexpr int CTX_QB = 128;  // query rows per workgroup
 
-// grid (ceil(max_len / 128), Hq, B), block 256
+// grid (ceil(max_len / 128), Hq, B), block 256.  blockIdx.x counts query tiles from the END of the sequence so the
+// long (many key tiles) workgroups are dispatched first.
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void ctx_attn_kernel(CtxArgs p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void ctx_attn_kernel(CtxArgs p)
 {
-    constexpr int KS = DH / 32;      // QK k-steps
-    constexpr int DT = DH / 16;      // output d-tiles
-    constexpr int ROWB = DH * 2;     // bytes of a V row in the LDS tile
-    constexpr int CH = ROWB / 16;    // 16-byte chunks per row: 16 / 8
-    __shared__ __attribute__((aligned(16))) uint8_t vt_all[4 * CTX_STEP * ROWB];
+    constexpr int KS = DH / 32;             // QK k-steps
+    constexpr int DT = DH / 16;             // output d-tiles
+    constexpr int ROWB = DH * 2;            // bytes of a K / V row
+    constexpr int CH = ROWB / 16;           // 16-byte chunks per row: 16 / 8
+    constexpr int TILE_BYTES = CTX_KT * ROWB; // one K (or V) tile: 16 / 8 KiB
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int RPD = 1024 / ROWB;        // rows per DMA instruction (64 lanes x 16 B): 4 / 8
+    constexpr int DPT = CTX_KT / RPD;       // DMA instructions per tile: 16 / 8
+    constexpr int DPW = DPT / 4;            // per wave: 4 / 2
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * STAGE_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -166,16 +361,66 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxArgs p)
     const int b = blockIdx.z, h = blockIdx.y;
     const int hk = h / (p.num_heads / p.num_kv_heads);
     const int len = p.ctx_lens[b];
-    const int q0 = blockIdx.x * CTX_QB + wave * CTX_QW; // this wave's first query row
-    if (q0 >= len) // wave-uniform; no barriers below
+    const int qtile = (int) gridDim.x - 1 - (int) blockIdx.x;
+    const int Q0 = qtile * CTX_QB;
+    if (Q0 >= len) // whole workgroup past the sequence
         return;
-    const int hidden = (p.num_heads + 2 * p.num_kv_heads) * DH;
+    const int q0 = Q0 + wave * CTX_QW; // this wave's first query row
+    const bool wave_live = q0 < len;
     const size_t row0 = (size_t) (p.offsets ? p.offsets[b] : b * p.max_len);
-    const uint16_t* qbase = p.proc + row0 * hidden + (size_t) h * DH;
-    const uint16_t* kbase = p.proc + row0 * hidden + (size_t) (p.num_heads + hk) * DH;
-    const uint16_t* vbase = p.proc + row0 * hidden + (size_t) (p.num_heads + p.num_kv_heads + hk) * DH;
-    uint8_t* vt = vt_all + wave * CTX_STEP * ROWB;
-    auto voff = [](int row, int ch) { return ROWB * row + 16 * (ch ^ ((((row & 3) << 2) | ((row >> 2) & 3)) & (CH - 1))); };
+    const uint16_t* qbase = p.proc + ((size_t) h * p.rows + row0) * DH;
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.proc + ((size_t) (p.num_heads + hk) * p.rows + row0) * DH);
+    const uint8_t* vbase
+        = reinterpret_cast<const uint8_t*>(p.proc + ((size_t) (p.num_heads + p.num_kv_heads + hk) * p.rows + row0) * DH);
+
+    // swizzles of the 16-byte chunk index by tile row.  K: 16 consecutive rows x one logical chunk (a ds_read_b128
+    // fragment) cover all 64 banks once.  V: the transposing 8-byte reads of 4 row groups do.
+    auto ksw = [](int row) { return CH == 16 ? (row & 15) : ((row >> 1) & 7); };
+    auto vsw = [](int row) { return (((row & 3) << 2) | ((row >> 2) & 3)) & (CH - 1); };
+
+    // ---- DMA staging: instruction d of a tile fills LDS bytes [1024 d, +1024): lane -> (row, stored chunk)
+    const int drow = lane / CH, dch = lane % CH;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) (ctx_lds_void_t*) lds);
+    uint32_t krel[DPW], vrel[DPW]; // byte offset of this lane's 16 bytes inside a full tile
+#pragma unroll
+    for (int i = 0; i < DPW; ++i)
+    {
+        const int row = (wave * DPW + i) * RPD + drow;
+        krel[i] = row * ROWB + 16 * (dch ^ ksw(row));
+        vrel[i] = row * ROWB + 16 * (dch ^ vsw(row));
+    }
+    auto stage = [&](int tile, int buf)
+    {
+        const int t0 = tile * CTX_KT;
+        if (t0 + CTX_KT <= len) // wave-uniform: the whole tile is inside the sequence
+        {
+            const uint8_t* kt = kbase + (size_t) t0 * ROWB;
+            const uint8_t* vt = vbase + (size_t) t0 * ROWB;
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+            {
+                const uint32_t kdst = lds_base + buf * STAGE_BYTES + (wave * DPW + i) * 1024;
+                ctx_dma16(kt + krel[i], kdst);
+                ctx_dma16(vt + vrel[i], kdst + TILE_BYTES);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+            {
+                const int d = wave * DPW + i;
+                const int row = d * RPD + drow;
+                const size_t grow = (size_t) min(t0 + row, len - 1) * ROWB; // rows past the sequence re-read its last row (masked)
+                const uint32_t kdst = lds_base + buf * STAGE_BYTES + d * 1024;
+                ctx_dma16(kbase + grow + 16 * (dch ^ ksw(row)), kdst);
+                ctx_dma16(vbase + grow + 16 * (dch ^ vsw(row)), kdst + TILE_BYTES);
+            }
+        }
+    };
+
+    const int kv_end = min(len, Q0 + CTX_QB); // causal: keys 0 .. last query row of the workgroup
+    const int ntiles = (kv_end + CTX_KT - 1) / CTX_KT;
 
     // Q^T fragments (B operand): column = query row q0 + 16*qt + lr, k = d = 32*ks + 8*lq + j
     uint4 qf[2][KS];
@@ -185,8 +430,16 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxArgs p)
         const int qr = min(q0 + 16 * qt + lr, len - 1); // rows past the sequence re-read its last row; never stored
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            qf[qt][ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * hidden + 32 * ks + 8 * lq);
+            qf[qt][ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * DH + 32 * ks + 8 * lq);
     }
+    // make the compiler's own vmcnt bookkeeping for the Q loads end here, before any (invisible to it) DMA is in flight:
+    // otherwise it places its waits for them at their first use inside the loop, where they would drain the prefetch
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            asm volatile("" : "+v"(qf[qt][ks].x), "+v"(qf[qt][ks].y), "+v"(qf[qt][ks].z), "+v"(qf[qt][ks].w));
+    stage(0, 0);
     const float sscale = p.score_scale * 1.4426950408889634f;
 
     float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
@@ -197,20 +450,21 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxArgs p)
         for (int dt = 0; dt < DT; ++dt)
             o[qt][dt] = cf32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int t_end = min(len, q0 + CTX_QW); // causal: keys 0 .. last query row of the wave
-    for (int t0 = 0; t0 < t_end; t0 += CTX_STEP)
+    const int rq = lr >> 2, rp = lr & 3;
+    auto compute = [&](int buf, int t0)
     {
-        const int tmax = len - 1 - t0;
+        const uint8_t* kt = lds + buf * STAGE_BYTES;
+        const uint8_t* vt = kt + TILE_BYTES;
         // ---- S^T tiles [key tile x][query tile qt]
-        cf32x4_t s[2][2];
+        cf32x4_t s[4][2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < 4; ++x)
         {
-            const uint16_t* krow = kbase + (size_t) (t0 + min(16 * x + lr, tmax)) * hidden + 8 * lq;
+            const int row = 16 * x + lr;
             uint4 kf[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                kf[ks] = *reinterpret_cast<const uint4*>(krow + 32 * ks);
+                kf[ks] = *reinterpret_cast<const uint4*>(kt + ROWB * row + 16 * ((4 * ks + lq) ^ ksw(row)));
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
             {
@@ -220,71 +474,102 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxArgs p)
                     s[x][qt] = ctx_mfma<T>(kf[ks], qf[qt][ks], s[x][qt]);
             }
         }
-        // ---- V tile -> LDS: rows (64 / CH) * i + lane / CH, chunk lane % CH
-        {
-            constexpr int RPI = 64 / CH; // rows per load instruction: 4 / 8
-#pragma unroll
-            for (int i = 0; i < CTX_STEP / RPI; ++i)
-            {
-                const int r = RPI * i + lane / CH, ch = lane % CH;
-                *reinterpret_cast<uint4*>(vt + voff(r, ch))
-                    = *reinterpret_cast<const uint4*>(vbase + (size_t) (t0 + min(r, tmax)) * hidden + 8 * ch);
-            }
-        }
-        // ---- causal mask + online softmax per query column
-        uint4 pf[2];
+        // ---- mask (only tiles that cross the diagonal or the end of the sequence) + online softmax per query column.
+        // The running maximum is kept on the RAW scores (sscale > 0) and the scale rides in the exponent's fma:
+        // p = exp2(s * sscale - m * sscale)
+        const bool need_mask = t0 + CTX_KT - 1 > q0 || t0 + CTX_KT > len; // wave-uniform
+        uint4 pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
         {
             const int qpos = q0 + 16 * qt + lr;
-            float mx = NEG_BIG;
+            if (need_mask)
+            {
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                    {
+                        const int t = t0 + 16 * x + 4 * lq + rr;
+                        s[x][qt][rr] = (t <= qpos && t < len) ? s[x][qt][rr] : NEG_BIG;
+                    }
+            }
+            float mx = ctx_max3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+            float my = ctx_max3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
+            mx = ctx_max3(mx, s[1][qt][2], s[1][qt][3]);
+            my = ctx_max3(my, s[2][qt][0], s[2][qt][1]);
+            mx = ctx_max3(mx, s[2][qt][2], s[2][qt][3]);
+            my = ctx_max3(my, s[3][qt][0], s[3][qt][1]);
+            mx = ctx_max3(mx, s[3][qt][2], s[3][qt][3]);
+            mx = ctx_max3(mx, my, __shfl_xor(ctx_max3(mx, my, my), 16));
+            const float m_new = ctx_max3(m_run[qt], mx, __shfl_xor(mx, 32));
+            if (__any(m_new > m_run[qt])) // wave-uniform: rescale only when some column's max moved
+            {
+                const float corr = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sscale);
+                m_run[qt] = m_new;
+                l_run[qt] *= corr;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        o[qt][dt][rr] *= corr;
+            }
+            // key 0 is visible to every query row, so m_run is a real score from the first tile on and a masked
+            // score gives exp2(-huge) = 0
+            const float msc = -m_run[qt] * sscale;
+            float pr[4][4];
+            float ls = 0.f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
                 {
-                    const int t = t0 + 16 * x + 4 * lq + rr;
-                    s[x][qt][rr] = (t <= qpos && t < len) ? s[x][qt][rr] * sscale : NEG_BIG;
-                    mx = fmaxf(mx, s[x][qt][rr]);
+                    pr[x][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[x][qt][rr], sscale, msc));
+                    ls += pr[x][rr];
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qt], mx);
-            const float corr = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
-            l_run[qt] *= corr;
+            l_run[qt] += ls;
+            // P^T fragments (B operand), one per 32 keys: k index j < 4 -> key 4*lq + j of tile 2kh, j >= 4 -> of tile 2kh+1
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+                pf[qt][kh] = make_uint4(pack2<T>(pr[2 * kh][0], pr[2 * kh][1]), pack2<T>(pr[2 * kh][2], pr[2 * kh][3]),
+                    pack2<T>(pr[2 * kh + 1][0], pr[2 * kh + 1][1]), pack2<T>(pr[2 * kh + 1][2], pr[2 * kh + 1][3]));
+        }
+        // ---- O^T += V^T . P^T  (A operand rows d = 16*dt + lr).  Transposing read: lane 4q'+p' of a 16-lane group
+        // supplies row r0 + q', columns 4p' .. 4p'+3 of the 16-column block; lane i receives column i of rows r0 .. r0+3
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+        {
+            const int ra = 32 * kh + 4 * lq + rq, rb = ra + 16;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    o[qt][dt][rr] *= corr;
-            float pA[4], pB[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
             {
-                // a fully masked column keeps m_new = NEG_BIG: exp2(NEG_BIG - NEG_BIG) = 1 would count masked keys
-                pA[rr] = s[0][qt][rr] > NEG_BIG * 0.5f ? __builtin_amdgcn_exp2f(s[0][qt][rr] - m_new) : 0.f;
-                pB[rr] = s[1][qt][rr] > NEG_BIG * 0.5f ? __builtin_amdgcn_exp2f(s[1][qt][rr] - m_new) : 0.f;
-                l_run[qt] += pA[rr] + pB[rr];
+                const int ch = 2 * dt + (rp >> 1), sub = 8 * (rp & 1);
+                const cs16x4_t va
+                    = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * ra + 16 * (ch ^ vsw(ra)) + sub));
+                const cs16x4_t vb
+                    = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * rb + 16 * (ch ^ vsw(rb)) + sub));
+                const uint2 a2 = __builtin_bit_cast(uint2, va), b2 = __builtin_bit_cast(uint2, vb);
+                const uint4 vf = make_uint4(a2.x, a2.y, b2.x, b2.y);
+                o[0][dt] = ctx_mfma<T>(vf, pf[0][kh], o[0][dt]);
+                o[1][dt] = ctx_mfma<T>(vf, pf[1][kh], o[1][dt]);
             }
-            pf[qt] = make_uint4(pack2<T>(pA[0], pA[1]), pack2<T>(pA[2], pA[3]), pack2<T>(pB[0], pB[1]), pack2<T>(pB[2], pB[3]));
         }
-        // ---- O^T += V^T . P^T  (A operand rows d = 16*dt + lr; k index j < 4 -> key 4*lq + j, j >= 4 -> key 16 + 4*lq + j - 4)
-        const int rq = lr >> 2, rp = lr & 3;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-        {
-            const int ch = 2 * dt + (rp >> 1), sub = 8 * (rp & 1);
-            const cs16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + voff(4 * lq + rq, ch) + sub));
-            const cs16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + voff(16 + 4 * lq + rq, ch) + sub));
-            const uint2 a2 = __builtin_bit_cast(uint2, va), b2 = __builtin_bit_cast(uint2, vb);
-            const uint4 vf = make_uint4(a2.x, a2.y, b2.x, b2.y);
-            o[0][dt] = ctx_mfma<T>(vf, pf[0], o[0][dt]);
-            o[1][dt] = ctx_mfma<T>(vf, pf[1], o[1][dt]);
-        }
+    };
+
+    for (int i = 0; i < ntiles; ++i)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of tile i has landed
+        __syncthreads();                                  // everyone's has, and everyone is done with tile i-1
+        if (i + 1 < ntiles)
+            stage(i + 1, (i + 1) & 1);
+        const int t0 = i * CTX_KT;
+        if (wave_live && t0 < q0 + CTX_QW) // wave-uniform: tiles past this wave's last row are fully masked
+            compute(i & 1, t0);
     }
 
     // ---- finish: sum over the 4 lanes of a column, normalise, store 4 consecutive d per lane
+    if (!wave_live)
+        return;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
     {
@@ -372,6 +657,8 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
             q.position_embedding_type);
     const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * q.head_size;
     const size_t tokens = q.remove_padding ? (size_t) q.num_tokens : (size_t) q.batch * q.max_context_length;
+    MQ_CHECK(tokens > 0 && tokens < (1u << 31), "token rows %zu", tokens);
+    a.rows = (int) tokens;
     a.proc = reinterpret_cast<uint16_t*>(q.workspace);
     if (q.remove_padding)
     {
@@ -381,9 +668,15 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     }
     const bool bf = q.act_type == MI355Q_BF16;
     const dim3 pgrid(q.max_context_length, q.batch);
-    const size_t plds = hidden * sizeof(float);
+    const size_t plds = (hidden + q.head_size) * sizeof(float);
     MQ_CHECK(plds <= 64 * 1024, "qkv hidden size %zu too large for the prepare kernel", hidden);
-    if (bf)
+    const bool fast = q.position_embedding_type == 0 || q.position_embedding_type == 1
+        || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size);
+    if (fast && bf)
+        hipLaunchKernelGGL(ctx_prepare_fast_kernel<bf16_t>, pgrid, dim3(256), 0, stream, a);
+    else if (fast)
+        hipLaunchKernelGGL(ctx_prepare_fast_kernel<f16_t>, pgrid, dim3(256), 0, stream, a);
+    else if (bf)
         hipLaunchKernelGGL(ctx_prepare_kernel<bf16_t>, pgrid, dim3(256), plds, stream, a);
     else
         hipLaunchKernelGGL(ctx_prepare_kernel<f16_t>, pgrid, dim3(256), plds, stream, a);

@@ -24,11 +24,12 @@ def make_inputs(lens, Hq, Hkv, D, dtype, seed=42):
     return [(torch.randn(n, (Hq + 2 * Hkv) * D, generator=g) * 0.5).to(dtype) for n in lens]
 
 
-def make_plugin(Hq, Hkv, D, dtype, kv_dtype, tpb, rope, bias, remove_padding, layer_idx=0, max_context_length=0):
+def make_plugin(Hq, Hkv, D, dtype, kv_dtype, tpb, rope, bias, remove_padding, layer_idx=0, max_context_length=0,
+                rot_dim=None):
     pe = {None: 0, "gptj": 1, "neox": 2}[rope]
     return F.make_gpt_attention_plugin(
         num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="float16" if dtype == torch.float16 else "bfloat16",
-        layer_idx=layer_idx, position_embedding_type=pe, rotary_embedding_dim=D if rope else 0,
+        layer_idx=layer_idx, position_embedding_type=pe, rotary_embedding_dim=(rot_dim or D) if rope else 0,
         kv_cache_quant_mode=QM.get(kv_dtype, 0), remove_input_padding=remove_padding, paged_kv_cache=True,
         tokens_per_block=tpb, qkv_bias_enabled=bias is not None, max_context_length=max_context_length)
 
@@ -102,15 +103,15 @@ def compare_cache(pool_after, cache, rope):
 
 
 def check(lens, Hq, Hkv, D, tpb, dtype, kv_dtype, dev, rope=None, with_bias=False, remove_padding=False,
-          num_layers=1, layer_idx=0, seed=42):
+          num_layers=1, layer_idx=0, seed=42, rot_dim=None):
     rows = make_inputs(lens, Hq, Hkv, D, dtype, seed)
     bias = (torch.randn((Hq + 2 * Hkv) * D) * 0.1).to(dtype) if with_bias else None
     kv_scale = 4.0 / 127.0 if kv_dtype == torch.int8 else 1.0
     cache = oracle.PagedKVCache(len(lens), Hkv, D, max(lens) + 24, tpb, kv_dtype, seed=seed)
     pool = cache.pool.to(dev)
-    plg = make_plugin(Hq, Hkv, D, dtype, kv_dtype, tpb, rope, bias, remove_padding, layer_idx)
+    plg = make_plugin(Hq, Hkv, D, dtype, kv_dtype, tpb, rope, bias, remove_padding, layer_idx, rot_dim=rot_dim)
     outs, _ = run_context(plg, rows, cache, pool, dev, kv_scale, remove_padding, bias, num_layers, layer_idx)
-    refs = oracle.context_attention(rows, lens, Hq, Hkv, D, cache=cache, rope=rope, rot_dim=D if rope else 0,
+    refs = oracle.context_attention(rows, lens, Hq, Hkv, D, cache=cache, rope=rope, rot_dim=(rot_dim or D) if rope else 0,
                                     qkv_bias=bias, kv_scale_orig_quant=1.0 / kv_scale)
     for b, (o, r) in enumerate(zip(outs, refs)):
         assert o.shape == r.shape
@@ -138,6 +139,14 @@ def test_context_8bit_cache(cuda, dtype, kv_dtype):
 def test_context_rope_and_bias(cuda, dtype, rope):
     check([77, 300], 8, 2, 128, 64, dtype, dtype, cuda, rope=rope, with_bias=True)
     check([77, 300], 4, 4, 64, 64, dtype, torch.int8, cuda, rope=rope)
+
+
+def test_context_partial_rotary(cuda):
+    # rotary_embedding_dim < head_size (GPT-J / GPT-NeoX style rotary_pct): NeoX takes the generic prepare kernel,
+    # GPT-J the vectorised one with pass-through elements
+    for rope in ("neox", "gptj"):
+        check([70, 33], 4, 2, 128, 64, torch.float16, torch.float16, cuda, rope=rope, rot_dim=64, with_bias=True)
+        check([70, 33], 4, 4, 64, 64, torch.bfloat16, torch.int8, cuda, rope=rope, rot_dim=32)
 
 
 def test_context_edge_lengths(cuda):
