@@ -48,6 +48,21 @@ __device__ __forceinline__ float ctx_max3(float a, float b, float c)
     return r;
 }
 
+// max over lane ^ 16 (W = 16) or lane ^ 32 (W = 32) through v_permlane{16,32}_swap: with both operands holding x
+// the two results are [x0 x0 x2 x2] / [x1 x1 x3 x3] by rows of 16 lanes (W = 16) or [lo lo] / [hi hi] by halves
+// (W = 32), so their max is the pairwise all-reduce.  The second operand goes through an empty asm: hipcc folds the
+// two results of the builtin into one when it can prove the operands equal.
+template <int W>
+__device__ __forceinline__ float ctx_swap_max(float x)
+{
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    asm("" : "+v"(b));
+    const auto r = W == 16 ? __builtin_amdgcn_permlane16_swap(a, b, false, false) : __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(__builtin_bit_cast(float, r[0])), "v"(__builtin_bit_cast(float, r[1])));
+    return m;
+}
+
 struct CtxArgs
 {
     const uint16_t* qkv;      // input rows [(Hq + 2 Hkv) * Dh]
@@ -337,13 +352,13 @@ __device__ __forceinline__ cf32x4_t ctx_mfma<f16_t>(const uint4& a, const uint4&
 
 constexpr int CTX_KT = 64;   // keys per tile
 constexpr int CTX_QW = 32;   // query rows per wave
-constexpr int CTX_QB = 128;  // query rows per workgroup
 
-// grid (ceil(max_len / 128), Hq, B), block 256.  blockIdx.x counts query tiles from the END of the sequence so the
+// grid (Hq, ceil(max_len / (32 NWV)), B), block 64 NWV.  blockIdx.y counts query tiles from the END of the sequence so the
 // long (many key tiles) workgroups are dispatched first.
-template <typename T, int DH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void ctx_attn_kernel(CtxArgs p)
+template <typename T, int DH, int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void ctx_attn_kernel(CtxArgs p)
 {
+    constexpr int CTX_QB = CTX_QW * NWV;    // query rows per workgroup: 128 (4 waves, short sequences) / 256 (8 waves)
     constexpr int KS = DH / 32;             // QK k-steps
     constexpr int DT = DH / 16;             // output d-tiles
     constexpr int ROWB = DH * 2;            // bytes of a K / V row
@@ -352,16 +367,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;
     constexpr int RPD = 1024 / ROWB;        // rows per DMA instruction (64 lanes x 16 B): 4 / 8
     constexpr int DPT = CTX_KT / RPD;       // DMA instructions per tile: 16 / 8
-    constexpr int DPW = DPT / 4;            // per wave: 4 / 2
+    constexpr int DPW = DPT / NWV;          // per wave
+    static_assert(DPT % NWV == 0, "tile pieces do not split evenly over the waves");
     __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * STAGE_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int hk = h / (p.num_heads / p.num_kv_heads);
+    // blockIdx.x enumerates the q heads kv-head-fastest: workgroups are dealt to the 8 XCDs round-robin in linear
+    // order, so an XCD gets the heads of kv-heads = its index (mod 8) for EVERY query tile -- equal work per XCD
+    // (the causal tiles differ 16:1 in length) and a kv-head's K / V stay in one XCD's L2
+    const int b = blockIdx.z;
+    const int hk = blockIdx.x % p.num_kv_heads;
+    const int h = hk * (p.num_heads / p.num_kv_heads) + blockIdx.x / p.num_kv_heads;
     const int len = p.ctx_lens[b];
-    const int qtile = (int) gridDim.x - 1 - (int) blockIdx.x;
+    const int qtile = (int) gridDim.y - 1 - (int) blockIdx.y;
     const int Q0 = qtile * CTX_QB;
     if (Q0 >= len) // whole workgroup past the sequence
         return;
@@ -501,8 +521,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             mx = ctx_max3(mx, s[2][qt][2], s[2][qt][3]);
             my = ctx_max3(my, s[3][qt][0], s[3][qt][1]);
             mx = ctx_max3(mx, s[3][qt][2], s[3][qt][3]);
-            mx = ctx_max3(mx, my, __shfl_xor(ctx_max3(mx, my, my), 16));
-            const float m_new = ctx_max3(m_run[qt], mx, __shfl_xor(mx, 32));
+            // all-reduce over the 4 lanes of the column (lane ^ 16, lane ^ 32) with the row-swap permutes: no LDS trip
+            mx = ctx_swap_max<16>(ctx_max3(mx, my, my));
+            const float m_new = ctx_max3(ctx_swap_max<32>(mx), m_run[qt], m_run[qt]);
             if (__any(m_new > m_run[qt])) // wave-uniform: rescale only when some column's max moved
             {
                 const float corr = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sscale);
@@ -570,6 +591,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     // ---- finish: sum over the 4 lanes of a column, normalise, store 4 consecutive d per lane
     if (!wave_live)
         return;
+
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
     {
@@ -680,15 +702,19 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
         hipLaunchKernelGGL(ctx_prepare_kernel<bf16_t>, pgrid, dim3(256), plds, stream, a);
     else
         hipLaunchKernelGGL(ctx_prepare_kernel<f16_t>, pgrid, dim3(256), plds, stream, a);
-    const dim3 agrid((q.max_context_length + CTX_QB - 1) / CTX_QB, q.num_heads, q.batch);
+    // 4 waves x 32 query rows per workgroup.  (8-wave workgroups -- lock-stepped, or the two halves run one segment
+    // apart so that a SIMD's two waves alternate matrix and VALU segments -- measured 3-8 % slower: DESIGN.md 4.4)
+    const dim3 agrid(q.num_heads, (q.max_context_length + 32 * 4 - 1) / (32 * 4), q.batch);
+#define MQ_CTX_LAUNCH(TT, DD) hipLaunchKernelGGL((ctx_attn_kernel<TT, DD, 4>), agrid, dim3(256), 0, stream, a)
     if (bf && q.head_size == 128)
-        hipLaunchKernelGGL((ctx_attn_kernel<bf16_t, 128>), agrid, dim3(256), 0, stream, a);
+        MQ_CTX_LAUNCH(bf16_t, 128);
     else if (bf)
-        hipLaunchKernelGGL((ctx_attn_kernel<bf16_t, 64>), agrid, dim3(256), 0, stream, a);
+        MQ_CTX_LAUNCH(bf16_t, 64);
     else if (q.head_size == 128)
-        hipLaunchKernelGGL((ctx_attn_kernel<f16_t, 128>), agrid, dim3(256), 0, stream, a);
+        MQ_CTX_LAUNCH(f16_t, 128);
     else
-        hipLaunchKernelGGL((ctx_attn_kernel<f16_t, 64>), agrid, dim3(256), 0, stream, a);
+        MQ_CTX_LAUNCH(f16_t, 64);
+#undef MQ_CTX_LAUNCH
     MQ_HIP(hipGetLastError());
 }
 
