@@ -96,6 +96,11 @@ extern "C"
      *   "QuantizePerToken"               {} plugins/quantizePerTokenPlugin/quantizePerTokenPlugin.cpp
      *   "GPTAttention"                   {layer_idx, num_heads, ... is_medusa_enabled}
      *        plugins/gptAttentionCommon/gptAttentionCommon.cpp:1561-1593, gptAttentionPlugin.cpp:700-790
+     *   "QuantizeTensor"                 {} plugins/quantizeTensorPlugin/quantizeTensorPlugin.cpp
+     *   "RmsnormQuantization"            {eps, dyn_act_scaling, type_id}
+     *        plugins/rmsnormQuantizationPlugin/rmsnormQuantizationPlugin.cpp:227-290
+     *   "LayernormQuantization"          {eps, use_diff_of_squares, dyn_act_scaling, type_id}
+     *        plugins/layernormQuantizationPlugin/layernormQuantizationPlugin.cpp:233-302
      *   "Fp8Gemm"  (no reference plugin: TensorRT fuses Q/DQ+matmul) {type_id}
      * Weight tensors handed to enqueue are in the layout mi355q_preprocess_weights_for_mixed_gemm
      * produces for MI355Q_LAYOUT_GFX950 (the arch-selected layout, as the reference selects per SM). */
@@ -208,6 +213,25 @@ extern "C"
     /* kernels/quantization.cu:118-127 invokePerTokenQuantization */
     mi355q_status mi355q_per_token_quantization(int8_t* dst, const void* src, int64_t numRows, int64_t numCols,
         float* scalePtr, int32_t src_type, void* stream);
+
+    /* kernels/quantization.cu:69-86 invokeQuantization(dst, src, size, scalePtr, stream, maxGridSize): static per-tensor
+     * int8 quantisation dst = cvt.rni.sat(src * *scalePtr); size must be a multiple of 4 (QuantizeTensor plugin). */
+    mi355q_status mi355q_quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scalePtr,
+        int32_t src_type, void* stream);
+
+    /* kernels/rmsnormKernels.cu:176-206 invokeGeneralRmsNorm(out, input, gamma, beta, eps, tokens, hidden_dim, stream,
+     * scale, dynamic_scale, normed_output_quant): out = T(x * rsqrt(mean(x^2) + eps) * gamma + beta); with
+     * dynamic_scale != NULL the row is quantised with 127 / amax(row) and dynamic_scale[row] = amax / 127, else with
+     * scale != NULL by *scale, into normed_output_quant (int8); with neither, `out` receives the T result.
+     * type: MI355Q_FLOAT / MI355Q_HALF (the reference's) / MI355Q_BF16.  beta may be NULL. */
+    mi355q_status mi355q_rms_norm(void* out, const void* input, const void* gamma, const void* beta, float eps,
+        int32_t tokens, int32_t hidden_dim, const float* scale, float* dynamic_scale, int8_t* normed_output_quant,
+        int32_t type, void* stream);
+    /* kernels/layernormKernels.cu:230-262 invokeGeneralLayerNorm(..., use_diff_of_squares, scale, dynamic_scale,
+     * normed_output_quant): same with (x - mean) and Var[x]; use_diff_of_squares selects E[x^2] - E[x]^2. */
+    mi355q_status mi355q_layer_norm(void* out, const void* input, const void* gamma, const void* beta, float eps,
+        int32_t tokens, int32_t hidden_dim, int32_t use_diff_of_squares, const float* scale, float* dynamic_scale,
+        int8_t* normed_output_quant, int32_t type, void* stream);
 
     /* FP8 e4m3 (OCP) GEMM: C[m,n] = cvt((sum_k A[m,k]*B[n,k]) * (scaleA*scaleB)); replaces the
      * TensorRT Q/DQ fusion / cuBLASLt fp8 path (plugins/gemmPlugin/gemmPlugin.cpp:193-198). */

@@ -491,3 +491,52 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
             out[:, h] = (p.double() @ v[:, hk]).float() / (p.sum(dim=1, keepdim=True) + 1e-6)
         outs.append(out.reshape(S, Hq * D).to(T))
     return outs
+
+
+# ----------------------------------------------------------------------------- norm + quantisation feeders
+def cast_int8_rni_sat(x):
+    """cuda_cast<int8_t, float>: cvt.rni.sat.s8.f32 (common/cudaTypeUtils.cuh)."""
+    return torch.clamp(torch.round(x.float()), -128, 127).to(torch.int8)
+
+
+def quantize_tensor(x, scale):
+    """kernels/quantization.cu:30-67 quantizedKernel: int8 = cvt.rni.sat(float(x) * scale)."""
+    return cast_int8_rni_sat(x.float() * np.float32(scale))
+
+
+def norm_quant(x, gamma, beta, eps, kind="rms", scale=None, dynamic=False, use_diff_of_squares=True):
+    """generalRmsNorm (kernels/rmsnormKernels.cu:52-150) / generalLayerNorm (layernormKernels.cu:60-192), restated:
+      statistics in fp32 (here: float64 sums rounded to fp32 -- the kernel's tree order is not part of the contract),
+      val = T(((x [- mean]) * rstd) * gamma + beta), every product / sum in fp32, one rounding to T;
+      dynamic: amax = max(|val|, T(1e-6)) per row, int8 = rni_sat(float(val) * (127 / amax)), scales = amax / 127;
+      static:  int8 = rni_sat(float(val) * scale);  neither: returns val.
+    x: torch [..., H] in T (float32 / float16 / bfloat16).  Returns (out, scales-or-None)."""
+    T = x.dtype
+    H = x.shape[-1]
+    xf = x.float().reshape(-1, H)
+    xd = xf.double()
+    if kind == "rms":
+        mean = None
+        rstd = torch.rsqrt(((xd * xd).sum(-1, keepdim=True) / H).float() + np.float32(eps))
+        cen = xf
+    else:
+        mean = (xd.sum(-1, keepdim=True) / H).float()
+        if use_diff_of_squares:
+            var = ((xd * xd).sum(-1, keepdim=True) / H).float() - mean * mean
+        else:
+            d = xd - mean.double()
+            var = ((d * d).sum(-1, keepdim=True) / H).float()
+        rstd = torch.rsqrt(var + np.float32(eps))
+        cen = xf - mean
+    val = (cen * rstd) * gamma.float().reshape(1, H)
+    if beta is not None:
+        val = val + beta.float().reshape(1, H)
+    val = val.to(T)
+    if dynamic:
+        floor = torch.tensor(1e-6, dtype=torch.float32).to(T).float()
+        amax = torch.maximum(val.float().abs().amax(-1, keepdim=True), floor)
+        q = cast_int8_rni_sat(val.float() * (np.float32(127.0) / amax))
+        return q.reshape(x.shape), (amax / np.float32(127.0)).reshape(*x.shape[:-1], 1)
+    if scale is not None:
+        return cast_int8_rni_sat(val.float() * np.float32(scale)).reshape(x.shape), None
+    return val.reshape(x.shape), None

@@ -48,6 +48,13 @@ void per_token_quantization(
 void quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols, int src_type, int mode,
     hipStream_t stream);
 
+// norm_quant.hip
+void rms_norm(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens, int hidden,
+    const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream);
+void layer_norm(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens, int hidden,
+    bool use_diff_of_squares, const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream);
+void quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scale, int type, hipStream_t stream);
+
 // decode_attn.hip
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q);
 void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream);

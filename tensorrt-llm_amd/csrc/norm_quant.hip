@@ -1,0 +1,419 @@
+// norm_quant.hip -- the feeders of the SmoothQuant GEMM, HBM-bound, one pass over the row:
+//   * RMSNorm / LayerNorm with fused int8 quantisation (static per-tensor scale or dynamic per-token scale):
+//     kernels/rmsnormKernels.cu:52-150 generalRmsNorm, kernels/layernormKernels.cu:60-192 generalLayerNorm
+//     (plugins rmsnormQuantizationPlugin.cpp:125-165, layernormQuantizationPlugin.cpp:128-170);
+//   * static per-tensor quantisation: kernels/quantization.cu:30-86 invokeQuantization (quantizeTensorPlugin.cpp:99-127).
+// Arithmetic follows the reference statement by statement: statistics in fp32, `val = T((x [- mean]) * rstd * gamma
+// + beta)` rounded to the activation type T, amax over |val| in T starting from 1e-6 (rounded to T), int8 =
+// cvt.rni.sat(float(val) * scale) with scale = *scale_orig_quant or 127 / amax, per-token scale out = amax / 127.
+// Layout: one workgroup of 256 threads per row; the row stays in registers between the statistics pass and the
+// output pass (16-byte loads, 8 elements per chunk), so HBM traffic is the algorithmic minimum: the row read once,
+// the int8 (or T) row written once.  Rows longer than 16384 or not a multiple of 8 take a re-reading scalar kernel.
+#include "kernels.h"
+
+namespace mi355q
+{
+namespace
+{
+
+template <typename T>
+struct NormIO;
+template <>
+struct NormIO<float>
+{
+    static __device__ __forceinline__ void load8(const void* base, size_t idx, float (&x)[8])
+    {
+        const float4* p = reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+        const float4 a = p[0], b = p[1];
+        x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+    }
+    static __device__ __forceinline__ float load1(const void* base, size_t idx)
+    {
+        return static_cast<const float*>(base)[idx];
+    }
+    static __device__ __forceinline__ float round(float v)
+    {
+        return v;
+    }
+    static __device__ __forceinline__ void store8(void* base, size_t idx, const float (&x)[8])
+    {
+        float4* p = reinterpret_cast<float4*>(static_cast<float*>(base) + idx);
+        p[0] = make_float4(x[0], x[1], x[2], x[3]);
+        p[1] = make_float4(x[4], x[5], x[6], x[7]);
+    }
+    static __device__ __forceinline__ void store1(void* base, size_t idx, float v)
+    {
+        static_cast<float*>(base)[idx] = v;
+    }
+};
+template <typename T>
+struct NormIO16
+{
+    static __device__ __forceinline__ void load8(const void* base, size_t idx, float (&x)[8])
+    {
+        const uint4 w = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(base) + idx);
+        const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            x[2 * i] = T16<T>::lo(u[i]);
+            x[2 * i + 1] = T16<T>::hi(u[i]);
+        }
+    }
+    static __device__ __forceinline__ float load1(const void* base, size_t idx)
+    {
+        return T16<T>::to_float(static_cast<const uint16_t*>(base)[idx]);
+    }
+    static __device__ __forceinline__ float round(float v)
+    {
+        return T16<T>::to_float(T16<T>::from_float(v));
+    }
+    static __device__ __forceinline__ void store8(void* base, size_t idx, const float (&x)[8])
+    {
+        *reinterpret_cast<uint4*>(static_cast<uint16_t*>(base) + idx)
+            = make_uint4(pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]), pack2<T>(x[4], x[5]), pack2<T>(x[6], x[7]));
+    }
+    static __device__ __forceinline__ void store1(void* base, size_t idx, float v)
+    {
+        static_cast<uint16_t*>(base)[idx] = T16<T>::from_float(v);
+    }
+};
+template <>
+struct NormIO<f16_t> : NormIO16<f16_t>
+{
+};
+template <>
+struct NormIO<bf16_t> : NormIO16<bf16_t>
+{
+};
+
+__device__ __forceinline__ uint32_t quant_rni_sat(float x)
+{
+    // cvt.rni.sat.s8.f32 (common/cudaTypeUtils.cuh cuda_cast<int8_t, float>)
+    float r = rintf(x);
+    r = fminf(fmaxf(r, -128.f), 127.f);
+    return (uint32_t) (uint8_t) (int8_t) (int) r;
+}
+
+struct NormArgs
+{
+    const void* input;
+    const void* gamma;
+    const void* beta; // or null
+    void* out;        // T [tokens, hidden] or null
+    int8_t* out_quant;
+    const float* scale_per_tensor; // or null
+    float* scale_per_token;        // or null
+    float eps;
+    int tokens, hidden;
+};
+
+// block-wide sum / max over 256 threads; every thread gets the result
+template <bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float* sm)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        const float o = __shfl_xor(v, off);
+        v = MAX ? fmaxf(v, o) : v + o;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads(); // sm may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0)
+        sm[wave] = v;
+    __syncthreads();
+    return MAX ? fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// MODE: 0 RMSNorm, 1 LayerNorm two-pass variance, 2 LayerNorm E[x^2] - E[x]^2 (use_diff_of_squares)
+template <typename T, int MODE, int VPT>
+__global__ __launch_bounds__(256) void norm_quant_kernel(NormArgs a)
+{
+    __shared__ float sm[4];
+    const size_t row = blockIdx.x;
+    const size_t base = row * a.hidden;
+    float x[VPT][8];
+    bool live[VPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < VPT; ++c)
+    {
+        const int i0 = (c * 256 + threadIdx.x) * 8;
+        live[c] = i0 < a.hidden;
+        if (live[c])
+        {
+            NormIO<T>::load8(a.input, base + i0, x[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                s1 += x[c][j];
+                s2 += x[c][j] * x[c][j];
+            }
+        }
+    }
+    float mean = 0.f, rstd;
+    if (MODE == 0)
+        rstd = rsqrtf(block_reduce<false>(s2, sm) / a.hidden + a.eps);
+    else if (MODE == 2)
+    {
+        mean = block_reduce<false>(s1, sm) / a.hidden;
+        rstd = rsqrtf(block_reduce<false>(s2, sm) / a.hidden - mean * mean + a.eps);
+    }
+    else
+    {
+        mean = block_reduce<false>(s1, sm) / a.hidden;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+            if (live[c])
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                {
+                    const float d = x[c][j] - mean;
+                    v += d * d;
+                }
+        rstd = rsqrtf(block_reduce<false>(v, sm) / a.hidden + a.eps);
+    }
+    // normalise, round to T
+    float amax = NormIO<T>::round(1e-6f);
+#pragma unroll
+    for (int c = 0; c < VPT; ++c)
+        if (live[c])
+        {
+            const int i0 = (c * 256 + threadIdx.x) * 8;
+            float g[8], b[8];
+            NormIO<T>::load8(a.gamma, i0, g);
+            if (a.beta)
+                NormIO<T>::load8(a.beta, i0, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                float v = (MODE == 0 ? x[c][j] : x[c][j] - mean) * rstd * g[j];
+                if (a.beta)
+                    v = v + b[j];
+                x[c][j] = NormIO<T>::round(v);
+                amax = fmaxf(amax, fabsf(x[c][j]));
+            }
+        }
+    float scale = 0.f;
+    if (a.scale_per_token)
+    {
+        amax = block_reduce<true>(amax, sm);
+        scale = 127.f / amax;
+        if (threadIdx.x == 0)
+            a.scale_per_token[row] = amax / 127.f;
+    }
+    else if (a.scale_per_tensor)
+        scale = a.scale_per_tensor[0];
+#pragma unroll
+    for (int c = 0; c < VPT; ++c)
+        if (live[c])
+        {
+            const int i0 = (c * 256 + threadIdx.x) * 8;
+            if (a.scale_per_token || a.scale_per_tensor)
+            {
+                uint32_t w[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    w[j >> 2] |= quant_rni_sat(x[c][j] * scale) << (8 * (j & 3));
+                *reinterpret_cast<uint2*>(a.out_quant + base + i0) = make_uint2(w[0], w[1]);
+            }
+            else
+                NormIO<T>::store8(a.out, base + i0, x[c]);
+        }
+}
+
+// any hidden size: scalar, re-reads the row (three or four passes served by L2)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void norm_quant_generic_kernel(NormArgs a)
+{
+    __shared__ float sm[4];
+    const size_t row = blockIdx.x;
+    const size_t base = row * a.hidden;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < a.hidden; i += 256)
+    {
+        const float v = NormIO<T>::load1(a.input, base + i);
+        s1 += v;
+        s2 += v * v;
+    }
+    float mean = 0.f, rstd;
+    if (MODE == 0)
+        rstd = rsqrtf(block_reduce<false>(s2, sm) / a.hidden + a.eps);
+    else if (MODE == 2)
+    {
+        mean = block_reduce<false>(s1, sm) / a.hidden;
+        rstd = rsqrtf(block_reduce<false>(s2, sm) / a.hidden - mean * mean + a.eps);
+    }
+    else
+    {
+        mean = block_reduce<false>(s1, sm) / a.hidden;
+        float v = 0.f;
+        for (int i = threadIdx.x; i < a.hidden; i += 256)
+        {
+            const float d = NormIO<T>::load1(a.input, base + i) - mean;
+            v += d * d;
+        }
+        rstd = rsqrtf(block_reduce<false>(v, sm) / a.hidden + a.eps);
+    }
+    auto normed = [&](int i)
+    {
+        float v = (MODE == 0 ? NormIO<T>::load1(a.input, base + i) : NormIO<T>::load1(a.input, base + i) - mean) * rstd
+            * NormIO<T>::load1(a.gamma, i);
+        if (a.beta)
+            v = v + NormIO<T>::load1(a.beta, i);
+        return NormIO<T>::round(v);
+    };
+    float scale = 0.f;
+    if (a.scale_per_token)
+    {
+        float amax = NormIO<T>::round(1e-6f);
+        for (int i = threadIdx.x; i < a.hidden; i += 256)
+            amax = fmaxf(amax, fabsf(normed(i)));
+        amax = block_reduce<true>(amax, sm);
+        scale = 127.f / amax;
+        if (threadIdx.x == 0)
+            a.scale_per_token[row] = amax / 127.f;
+    }
+    else if (a.scale_per_tensor)
+        scale = a.scale_per_tensor[0];
+    for (int i = threadIdx.x; i < a.hidden; i += 256)
+    {
+        const float v = normed(i);
+        if (a.scale_per_token || a.scale_per_tensor)
+            a.out_quant[base + i] = (int8_t) quant_rni_sat(v * scale);
+        else
+            NormIO<T>::store1(a.out, base + i, v);
+    }
+}
+
+template <typename T, int MODE>
+void launch_norm(const NormArgs& a, hipStream_t stream)
+{
+    const dim3 grid(a.tokens), block(256);
+    if (a.hidden % 8 != 0 || a.hidden > 16384)
+        hipLaunchKernelGGL((norm_quant_generic_kernel<T, MODE>), grid, block, 0, stream, a);
+    else if (a.hidden <= 2048)
+        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 1>), grid, block, 0, stream, a);
+    else if (a.hidden <= 4096)
+        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 2>), grid, block, 0, stream, a);
+    else if (a.hidden <= 8192)
+        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 4>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 8>), grid, block, 0, stream, a);
+    MQ_HIP(hipGetLastError());
+}
+
+template <int MODE>
+void dispatch_norm(const NormArgs& a, int type, hipStream_t stream)
+{
+    switch (type)
+    {
+    case MI355Q_FLOAT: launch_norm<float, MODE>(a, stream); break;
+    case MI355Q_HALF: launch_norm<f16_t, MODE>(a, stream); break;
+    case MI355Q_BF16: launch_norm<bf16_t, MODE>(a, stream); break;
+    default: MQ_CHECK(false, "norm: unsupported data type %d (float, half, bf16)", type);
+    }
+}
+
+NormArgs make_norm_args(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens,
+    int hidden, const float* scale, float* dynamic_scale, int8_t* out_quant)
+{
+    MQ_CHECK(input && gamma, "null input / gamma");
+    MQ_CHECK(tokens >= 0 && hidden > 0, "tokens %d hidden %d", tokens, hidden);
+    if (scale || dynamic_scale)
+        MQ_CHECK(out_quant, "a quantised output buffer is needed with scale / dynamic_scale");
+    else
+        MQ_CHECK(out, "null output");
+    NormArgs a{};
+    a.input = input;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.out = out;
+    a.out_quant = out_quant;
+    a.scale_per_tensor = dynamic_scale ? nullptr : scale; // per-token scaling wins, generalRmsNorm :110-126
+    a.scale_per_token = dynamic_scale;
+    a.eps = eps;
+    a.tokens = tokens;
+    a.hidden = hidden;
+    return a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_tensor_kernel(int8_t* dst, const void* src, int64_t chunks, const float* scale_ptr)
+{
+    const float scale = scale_ptr[0];
+    for (int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x; c < chunks; c += (int64_t) gridDim.x * 256)
+    {
+        float x[8];
+        NormIO<T>::load8(src, (size_t) c * 8, x);
+        uint32_t w[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w[j >> 2] |= quant_rni_sat(x[j] * scale) << (8 * (j & 3));
+        *reinterpret_cast<uint2*>(dst + c * 8) = make_uint2(w[0], w[1]);
+    }
+}
+
+template <typename T>
+__global__ void quantize_tensor_tail_kernel(int8_t* dst, const void* src, int64_t from, int64_t size, const float* scale_ptr)
+{
+    const int64_t i = from + threadIdx.x;
+    if (i < size)
+        dst[i] = (int8_t) quant_rni_sat(NormIO<T>::load1(src, (size_t) i) * scale_ptr[0]);
+}
+
+template <typename T>
+void launch_quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scale, hipStream_t stream)
+{
+    const int64_t chunks = size / 8;
+    if (chunks > 0)
+    {
+        const int blocks = (int) std::min<int64_t>((chunks + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(quantize_tensor_kernel<T>, dim3(blocks), dim3(256), 0, stream, dst, src, chunks, scale);
+    }
+    if (size % 8)
+        hipLaunchKernelGGL(quantize_tensor_tail_kernel<T>, dim3(1), dim3(64), 0, stream, dst, src, chunks * 8, size, scale);
+    MQ_HIP(hipGetLastError());
+}
+
+} // namespace
+
+void rms_norm(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens, int hidden,
+    const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream)
+{
+    if (tokens == 0) // empty batch: the tensors may have no storage
+        return;
+    const NormArgs a = make_norm_args(out, input, gamma, beta, eps, tokens, hidden, scale, dynamic_scale, out_quant);
+    dispatch_norm<0>(a, type, stream);
+}
+
+void layer_norm(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens, int hidden,
+    bool use_diff_of_squares, const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream)
+{
+    if (tokens == 0)
+        return;
+    const NormArgs a = make_norm_args(out, input, gamma, beta, eps, tokens, hidden, scale, dynamic_scale, out_quant);
+    if (use_diff_of_squares)
+        dispatch_norm<2>(a, type, stream);
+    else
+        dispatch_norm<1>(a, type, stream);
+}
+
+void quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scale, int type, hipStream_t stream)
+{
+    MQ_CHECK(size % 4 == 0, "[ERROR][invokeQuantization] size should be a multiple of 4.");
+    if (size == 0)
+        return;
+    MQ_CHECK(dst && src && scale, "null argument");
+    switch (type)
+    {
+    case MI355Q_FLOAT: launch_quantize_tensor<float>(dst, src, size, scale, stream); break;
+    case MI355Q_HALF: launch_quantize_tensor<f16_t>(dst, src, size, scale, stream); break;
+    case MI355Q_BF16: launch_quantize_tensor<bf16_t>(dst, src, size, scale, stream); break;
+    default: MQ_CHECK(false, "quantize_tensor: unsupported data type %d", type);
+    }
+}
+
+} // namespace mi355q

@@ -495,6 +495,146 @@ struct QuantizePerTokenPlugin : PluginBase
     void serialize(char*) const override {}
 };
 
+// ===================================================================== QuantizeTensor
+// plugins/quantizeTensorPlugin/quantizeTensorPlugin.cpp: inputs activation [M(*), K] (float / half), scale [1, 1] fp32;
+// output int8 [M(*), K]
+struct QuantizeTensorPlugin : PluginBase
+{
+    const char* type() const override
+    {
+        return "QuantizeTensor";
+    }
+    PluginBase* clone() const override
+    {
+        return new QuantizeTensorPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int nbIn, mi355q_dims* out) const override // :51-66
+    {
+        MQ_CHECK(nbIn == 2 && idx < 1, "nbInputs / outputIndex");
+        *out = in[0];
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override // :68-85
+    {
+        switch (pos)
+        {
+        case 0:
+            return (io[0].type == MI355Q_FLOAT || io[0].type == MI355Q_HALF || io[0].type == MI355Q_BF16)
+                && io[0].format == 0;
+        case 1: return io[1].type == MI355Q_FLOAT && io[1].format == 0;
+        case 2: return io[2].type == MI355Q_INT8 && io[2].format == 0;
+        default: MQ_CHECK(false, "pos %d", pos); return false;
+        }
+    }
+    int getOutputDataType(int idx, const int32_t*, int nbIn) const override
+    {
+        MQ_CHECK(nbIn == 2 && idx == 0, "nbInputs / index");
+        return MI355Q_INT8;
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override // :99-127
+    {
+        const int64_t numElts = dims_prod(inDesc[0].dims, 0, inDesc[0].dims.nbDims);
+        quantize_tensor(static_cast<int8_t*>(outputs[0]), inputs[0], numElts, static_cast<const float*>(inputs[1]),
+            inDesc[0].type, stream);
+    }
+    size_t serializationSize() const override
+    {
+        return 0;
+    }
+    void serialize(char*) const override {}
+};
+
+// ===================================================================== RmsnormQuantization / LayernormQuantization
+// plugins/rmsnormQuantizationPlugin/rmsnormQuantizationPlugin.cpp, plugins/layernormQuantizationPlugin/...:
+// inputs: input [M(*), N], weight [N], bias [N] (activation type), scale_to_int [1] fp32;
+// outputs: int8 [M(*), N], and with dyn_act_scaling the per-token scales [M(*), 1] fp32
+struct NormQuantizationPlugin : PluginBase
+{
+    bool mLayer; // LayerNorm (else RMSNorm)
+    float mEps;
+    bool mUseDiffOfSquares, mDynActScaling;
+    int32_t mType;
+    NormQuantizationPlugin(bool layer, float eps, bool diffOfSquares, bool dyn, int type)
+        : mLayer(layer)
+        , mEps(eps)
+        , mUseDiffOfSquares(diffOfSquares)
+        , mDynActScaling(dyn)
+        , mType(type)
+    {
+        // the reference enqueues kHALF and kFLOAT only (rmsnormQuantizationPlugin.cpp:149-162); bf16 is an extension
+        if (mType != MI355Q_HALF && mType != MI355Q_FLOAT && mType != MI355Q_BF16)
+            MQ_UNSUPPORTED("%s: unsupported data type %d", type_name(), mType);
+    }
+    const char* type_name() const
+    {
+        return mLayer ? "LayernormQuantization" : "RmsnormQuantization";
+    }
+    const char* type() const override
+    {
+        return type_name();
+    }
+    int nbOutputs() const override
+    {
+        return 1 + (mDynActScaling ? 1 : 0);
+    }
+    PluginBase* clone() const override
+    {
+        return new NormQuantizationPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int, mi355q_dims* out) const override // :60-87
+    {
+        MQ_CHECK(idx == 0 || (idx == 1 && mDynActScaling), "outputIndex %d", idx);
+        *out = in[0];
+        if (idx == 1)
+            out->d[in[0].nbDims - 1] = 1;
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int) const override // :89-112
+    {
+        const int totalPoses = 6 + (mDynActScaling ? 1 : 0);
+        MQ_CHECK(0 <= pos && pos < totalPoses, "pos %d", pos);
+        MQ_CHECK(nbIn == 4, "nbInputs %d", nbIn);
+        if (pos < 3)
+            return io[pos].type == mType && io[pos].format == 0;
+        if (pos == 3)
+            return io[pos].type == MI355Q_FLOAT && io[pos].format == 0;
+        if (pos == 4)
+            return io[pos].type == MI355Q_INT8 && io[pos].format == 0;
+        return io[pos].type == MI355Q_FLOAT && io[pos].format == 0;
+    }
+    int getOutputDataType(int idx, const int32_t*, int) const override
+    {
+        MQ_CHECK((mDynActScaling && idx < 2) || (!mDynActScaling && idx == 0), "index %d", idx);
+        return idx == 0 ? MI355Q_INT8 : MI355Q_FLOAT;
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override // :125-165
+    {
+        const int m = rows_of(inDesc[0].dims);
+        const int n = inDesc[1].dims.d[0];
+        MQ_CHECK(inDesc[0].dims.d[inDesc[0].dims.nbDims - 1] == n, "weight length %d != hidden size", n);
+        const float* scale = static_cast<const float*>(inputs[3]);
+        float* dynamic_scale = mDynActScaling ? static_cast<float*>(outputs[1]) : nullptr;
+        int8_t* output = static_cast<int8_t*>(outputs[0]);
+        if (mLayer)
+            layer_norm(nullptr, inputs[0], inputs[1], inputs[2], mEps, m, n, mUseDiffOfSquares, scale, dynamic_scale,
+                output, mType, stream);
+        else
+            rms_norm(nullptr, inputs[0], inputs[1], inputs[2], mEps, m, n, scale, dynamic_scale, output, mType, stream);
+    }
+    size_t serializationSize() const override // float eps, [bool use_diff_of_squares,] bool dyn, int32 type
+    {
+        return sizeof(float) + (mLayer ? 1 : 0) + 1 + sizeof(int32_t);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mEps);
+        if (mLayer)
+            write(buf, mUseDiffOfSquares);
+        write(buf, mDynActScaling);
+        write(buf, mType);
+    }
+};
+
 // ===================================================================== Fp8Gemm (no reference plugin)
 // inputs: 0 A e4m3 [.., K]; 1 B e4m3 [N, K]; 2 scale_a fp32 [1]; 3 scale_b fp32 [1]
 struct Fp8GemmPlugin : PluginBase
@@ -963,7 +1103,8 @@ GptAttentionFields parse_attention_fields(const FieldReader& r) // gptAttentionP
 }
 
 const char* const kPluginNames[] = {"WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
-    "QuantizePerToken", "GPTAttention", "Fp8Gemm", nullptr};
+    "QuantizePerToken", "GPTAttention", "Fp8Gemm", "QuantizeTensor", "RmsnormQuantization", "LayernormQuantization",
+    nullptr};
 
 PluginBase* create_plugin(const char* name, const FieldReader& r)
 {
@@ -985,6 +1126,14 @@ PluginBase* create_plugin(const char* name, const FieldReader& r)
         return new GPTAttentionPlugin(parse_attention_fields(r));
     if (n == "Fp8Gemm")
         return new Fp8GemmPlugin(r.req_int("type_id"));
+    if (n == "QuantizeTensor")
+        return new QuantizeTensorPlugin();
+    if (n == "RmsnormQuantization") // createPlugin, rmsnormQuantizationPlugin.cpp:253-290
+        return new NormQuantizationPlugin(
+            false, r.opt_float("eps", 1e-5f), false, r.req_int("dyn_act_scaling") != 0, r.req_int("type_id"));
+    if (n == "LayernormQuantization") // layernormQuantizationPlugin.cpp:260-302
+        return new NormQuantizationPlugin(true, r.opt_float("eps", 1e-5f), r.opt_int("use_diff_of_squares", 1) != 0,
+            r.req_int("dyn_act_scaling") != 0, r.req_int("type_id"));
     MQ_CHECK(false, "unknown plugin '%s'", name);
     return nullptr;
 }
@@ -1051,6 +1200,25 @@ PluginBase* deserialize_plugin(const char* name, const void* data, size_t length
         int32_t t;
         read(d, t);
         out = new Fp8GemmPlugin(t);
+    }
+    else if (n == "QuantizeTensor")
+    {
+        need(0);
+        out = new QuantizeTensorPlugin();
+    }
+    else if (n == "RmsnormQuantization" || n == "LayernormQuantization")
+    {
+        const bool layer = n == "LayernormQuantization";
+        need(sizeof(float) + (layer ? 1 : 0) + 1 + sizeof(int32_t));
+        float eps;
+        bool diff = false, dyn;
+        int32_t t;
+        read(d, eps);
+        if (layer)
+            read(d, diff);
+        read(d, dyn);
+        read(d, t);
+        out = new NormQuantizationPlugin(layer, eps, diff, dyn, t);
     }
     else
         MQ_CHECK(false, "unknown plugin '%s'", name);
@@ -1343,6 +1511,36 @@ extern "C"
     {
         return guarded(
             [&] { quantize_e4m3(dst, scales, src, rows, cols, src_type, mode, static_cast<hipStream_t>(stream)); });
+    }
+
+    mi355q_status mi355q_quantize_tensor(
+        int8_t* dst, const void* src, int64_t size, const float* scalePtr, int32_t src_type, void* stream)
+    {
+        return guarded([&] { quantize_tensor(dst, src, size, scalePtr, src_type, static_cast<hipStream_t>(stream)); });
+    }
+
+    mi355q_status mi355q_rms_norm(void* out, const void* input, const void* gamma, const void* beta, float eps,
+        int32_t tokens, int32_t hidden_dim, const float* scale, float* dynamic_scale, int8_t* normed_output_quant,
+        int32_t type, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                rms_norm(out, input, gamma, beta, eps, tokens, hidden_dim, scale, dynamic_scale, normed_output_quant, type,
+                    static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_layer_norm(void* out, const void* input, const void* gamma, const void* beta, float eps,
+        int32_t tokens, int32_t hidden_dim, int32_t use_diff_of_squares, const float* scale, float* dynamic_scale,
+        int8_t* normed_output_quant, int32_t type, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                layer_norm(out, input, gamma, beta, eps, tokens, hidden_dim, use_diff_of_squares != 0, scale,
+                    dynamic_scale, normed_output_quant, type, static_cast<hipStream_t>(stream));
+            });
     }
 
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params)

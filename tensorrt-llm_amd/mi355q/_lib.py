@@ -136,6 +136,9 @@ SYMBOLS = {
     "mi355q_apply_per_channel_scale": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mi355q_int8_gemm": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_per_token_quantization": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp]),
+    "mi355q_quantize_tensor": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
+    "mi355q_rms_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "mi355q_layer_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mi355q_fp8_gemm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_quantize_e4m3": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_decode_attention_workspace_size": (_sz, [C.POINTER(DecodeAttentionParams)]),

@@ -1,8 +1,9 @@
 """Host-side mirror of the reference's Python callers of the hot path, executing eagerly.
 
 Same names, argument order and meaning as
-  tensorrt_llm/quantization/functional.py:27-188, 332-359   (smooth_quant_gemm,
-      weight_only_quant_matmul, weight_only_groupwise_quant_matmul, quantize_per_token)
+  tensorrt_llm/quantization/functional.py:27-359   (smooth_quant_gemm, weight_only_quant_matmul,
+      weight_only_groupwise_quant_matmul, smooth_quant_layer_norm, smooth_quant_rms_norm, quantize_tensor,
+      quantize_per_token)
   tensorrt_llm/functional.py:3487-3930                      (gpt_attention, generation phase)
   torch.ops.trtllm.* of cpp/tensorrt_llm/thop/weightOnlyQuantOp.cpp
 so the parity tests read like the reference's own tests.  Every function forwards to the C ABI
@@ -149,6 +150,71 @@ def smooth_quant_gemm(input, weights, scales_a, scales_b, per_token_scaling, per
 def quantize_per_token(x):
     """quantization/functional.py:332-359: returns (int8 tensor, fp32 per-token scales [.., 1])."""
     return Plugin("QuantizePerToken")(x)
+
+
+def quantize_tensor(x, scale_factor):
+    """quantization/functional.py:297-329 `quantize_tensor` (QuantizeTensor plugin): static per-tensor int8."""
+    return Plugin("QuantizeTensor")(x, scale_factor)
+
+
+def _norm_dtype(input, dtype):
+    return dtype if dtype is not None else {torch.float16: "float16", torch.bfloat16: "bfloat16",
+                                            torch.float32: "float32"}[input.dtype]
+
+
+def smooth_quant_rms_norm(input, normalized_shape, weight=None, bias=None, scale=None, eps=1e-05,
+                          dynamic_act_scaling=False, dtype=None):
+    """quantization/functional.py:247-294: RmsnormQuantization plugin; weight / bias default to ones / zeros like
+    there.  Returns int8, or (int8, per-token scales [.., 1]) with dynamic_act_scaling."""
+    n = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[-1]
+    dtype = _norm_dtype(input, dtype)
+    plg = Plugin("RmsnormQuantization", [("eps", float(eps), L.FIELD_FLOAT32),
+                                         ("dyn_act_scaling", int(dynamic_act_scaling), L.FIELD_INT32),
+                                         ("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32)])
+    if weight is None:
+        weight = torch.ones(n, dtype=input.dtype, device=input.device)
+    if bias is None:
+        bias = torch.zeros(n, dtype=input.dtype, device=input.device)
+    return plg(input, weight, bias, scale)
+
+
+def smooth_quant_layer_norm(input, normalized_shape, weight=None, bias=None, scale=None, eps=1e-05,
+                            use_diff_of_squares=True, dynamic_act_scaling=False, dtype=None):
+    """quantization/functional.py:191-244: LayernormQuantization plugin."""
+    n = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[-1]
+    dtype = _norm_dtype(input, dtype)
+    plg = Plugin("LayernormQuantization", [("eps", float(eps), L.FIELD_FLOAT32),
+                                           ("use_diff_of_squares", int(use_diff_of_squares), L.FIELD_INT32),
+                                           ("dyn_act_scaling", int(dynamic_act_scaling), L.FIELD_INT32),
+                                           ("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32)])
+    if weight is None:
+        weight = torch.ones(n, dtype=input.dtype, device=input.device)
+    if bias is None:
+        bias = torch.zeros(n, dtype=input.dtype, device=input.device)
+    return plg(input, weight, bias, scale)
+
+
+def rms_norm(input, weight, bias=None, eps=1e-05):
+    """invokeGeneralRmsNorm without quantisation (the launcher below the plugins): T out."""
+    x = input.contiguous()
+    out = torch.empty_like(x)
+    h = x.shape[-1]
+    L.check(L.lib().mi355q_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                                    bias.data_ptr() if bias is not None else None, float(eps), x.numel() // h, h,
+                                    None, None, None, torch_dtype_to_trt(x.dtype), current_stream_ptr()))
+    return out
+
+
+def layer_norm(input, weight, bias=None, eps=1e-05, use_diff_of_squares=True):
+    """invokeGeneralLayerNorm without quantisation: T out."""
+    x = input.contiguous()
+    out = torch.empty_like(x)
+    h = x.shape[-1]
+    L.check(L.lib().mi355q_layer_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, float(eps), x.numel() // h, h,
+                                      int(use_diff_of_squares), None, None, None, torch_dtype_to_trt(x.dtype),
+                                      current_stream_ptr()))
+    return out
 
 
 def fp8_gemm(input, weights, scale_a, scale_b, dtype="float16"):

@@ -201,6 +201,35 @@ def test_attention_plugin_entry_indexing_and_errors():
                     [torch.zeros(B, 1, 8 * 64, dtype=torch.float16)])
 
 
+def test_feeder_plugins_shapes_formats_and_serialization():
+    # RmsnormQuantization / LayernormQuantization / QuantizeTensor (host-only: no launch)
+    rms = Plugin("RmsnormQuantization", [("eps", 1e-6, L.FIELD_FLOAT32), ("dyn_act_scaling", 1, L.FIELD_INT32),
+                                         ("type_id", L.HALF, L.FIELD_INT32)])
+    assert rms.nb_outputs == 2
+    shapes = [[2, 5, 10, 10], [10], [10], [1]]
+    assert rms.get_output_dimensions(0, shapes) == [2, 5, 10, 10]
+    assert rms.get_output_dimensions(1, shapes) == [2, 5, 10, 1]
+    assert rms.get_output_data_type(0, [L.HALF, L.HALF, L.HALF, L.FLOAT]) == L.INT8
+    assert rms.get_output_data_type(1, [L.HALF, L.HALF, L.HALF, L.FLOAT]) == L.FLOAT
+    blob = rms.serialize()  # float eps, bool dyn, int32 type (rmsnormQuantizationPlugin.cpp:205-217)
+    assert len(blob) == 9 and np.frombuffer(blob[:4], np.float32)[0] == np.float32(1e-6) and blob[4] == 1
+    assert Plugin.deserialize("RmsnormQuantization", blob).serialize() == blob
+    ln = Plugin("LayernormQuantization", [("eps", 1e-5, L.FIELD_FLOAT32), ("use_diff_of_squares", 0, L.FIELD_INT32),
+                                          ("dyn_act_scaling", 0, L.FIELD_INT32), ("type_id", L.FLOAT, L.FIELD_INT32)])
+    assert ln.nb_outputs == 1 and len(ln.serialize()) == 10
+    assert Plugin.deserialize("LayernormQuantization", ln.serialize()).serialize() == ln.serialize()
+    descs = Plugin._descs([torch.empty(4, 64), torch.empty(64), torch.empty(64), torch.empty(1),
+                           torch.empty(4, 64, dtype=torch.int8)])
+    assert all(ln.supports_format_combination(i, descs, 4, 1) for i in range(5))
+    descs[1].type = L.HALF
+    assert not ln.supports_format_combination(1, descs, 4, 1)
+    with pytest.raises(L.Mi355qError, match="unsupported data type"):
+        Plugin("RmsnormQuantization", [("dyn_act_scaling", 0, L.FIELD_INT32), ("type_id", L.INT8, L.FIELD_INT32)])
+    qt = Plugin("QuantizeTensor")
+    assert qt.nb_outputs == 1 and qt.get_output_dimensions(0, [[3, 8], [1, 1]]) == [3, 8]
+    assert qt.get_output_data_type(0, [L.HALF, L.FLOAT]) == L.INT8 and qt.serialize() == b""
+
+
 def test_allreduce_strategy_selection_matches_reference():
     # plugins/ncclPlugin/allreducePlugin.cpp:111-139
     sel = L.lib().mi355q_allreduce_select_implementation
