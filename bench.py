@@ -190,6 +190,35 @@ def bench_prefill_w4a16(dev, steps, m=4096, n=11008, k=4096, g=128):
             "frac_of_bf16_peak": ops / (dev_s / steps) / 1e12 / 2500.0}
 
 
+def bench_rmsnorm_quant(dev, steps, tokens=4096, hidden=5120, sets=24):
+    """8f rank 2: RMSNorm + dynamic per-token int8 quantisation, the cfg3 GEMM's feeder (Llama-2-13B hidden).
+    Algorithmic bytes per call: tokens*hidden*(2 in + 1 out) + hidden*2*2 (gamma, beta) + tokens*4 (scales);
+    rotating input sets (> 256 MB in total) keep the Infinity Cache out of the number."""
+    from mi355q import _lib as L
+    import ctypes as C
+    torch.manual_seed(0)
+    xs = [torch.randn(tokens, hidden, device=dev).to(torch.float16) for _ in range(sets)]
+    gamma = torch.rand(hidden, device=dev).to(torch.float16)
+    beta = torch.zeros(hidden, device=dev, dtype=torch.float16)
+    one = torch.ones(1, device=dev)
+    q = torch.empty(tokens, hidden, dtype=torch.int8, device=dev)
+    sc = torch.empty(tokens, 1, dtype=torch.float32, device=dev)
+    it = [0]
+    fn = L.lib().mi355q_rms_norm
+    ptrs = [x.data_ptr() for x in xs]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step():  # the launcher below the plugin (invokeGeneralRmsNorm's signature): the kernel is 20 us, keep the host out
+        rc = fn(None, ptrs[it[0] % sets], gamma.data_ptr(), beta.data_ptr(), 1e-5, tokens, hidden, one.data_ptr(),
+                sc.data_ptr(), q.data_ptr(), L.HALF, stream)
+        assert rc == 0
+        it[0] += 1
+    _, dev_s = time_steps(step, steps, sets, lambda: None)
+    algo = tokens * hidden * 3 + hidden * 4 + tokens * 4
+    return {"tokens": tokens, "hidden": hidden, "us_per_call": dev_s / steps * 1e6, "GBps": algo / (dev_s / steps) / 1e9,
+            "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo}
+
+
 def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16"):
     """8f rank 1: context (prefill) attention, Llama-2-7B heads: bias-less RoPE + paged KV append + causal
     attention; flops counted on the causal half (2 * 2 * S^2/2 * D per head)."""
@@ -326,6 +355,7 @@ def main():
                                      bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6)]
                 sec["int8_gemm"] = [bench_int8_gemm(dev, 10), bench_int8_gemm(dev, 10, n=5120, k=13824)]
                 sec["fp8_gemm"] = [bench_fp8_gemm(dev, 10), bench_fp8_gemm(dev, 10, n=4096, k=14336)]
+                sec["rmsnorm_quant"] = [bench_rmsnorm_quant(dev, 96), bench_rmsnorm_quant(dev, 96, hidden=8192, sets=16)]
                 sec["context_attention"] = [bench_context_attention(dev, 10),
                                             bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8")]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
