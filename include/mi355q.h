@@ -101,6 +101,8 @@ extern "C"
      *        plugins/rmsnormQuantizationPlugin/rmsnormQuantizationPlugin.cpp:227-290
      *   "LayernormQuantization"          {eps, use_diff_of_squares, dyn_act_scaling, type_id}
      *        plugins/layernormQuantizationPlugin/layernormQuantizationPlugin.cpp:233-302
+     *   "AllReduce"                      {group, type_id, strategy, counter} (+ optional "rank")
+     *        plugins/ncclPlugin/allreducePlugin.cpp:141-203, 286-350 (one-shot / two-shot; RING is the host's RCCL call)
      *   "Fp8Gemm"  (no reference plugin: TensorRT fuses Q/DQ+matmul) {type_id}
      * Weight tensors handed to enqueue are in the layout mi355q_preprocess_weights_for_mixed_gemm
      * produces for MI355Q_LAYOUT_GFX950 (the arch-selected layout, as the reference selects per SM). */
@@ -317,6 +319,46 @@ extern "C"
     }; /* AllReduceStrategyType, kernels/customAllReduceKernels.h */
     /* AllreducePlugin::selectImplementation (plugins/ncclPlugin/allreducePlugin.cpp:111-139) */
     int32_t mi355q_allreduce_select_implementation(size_t messageBytes, int32_t worldSize, size_t maxWorkspaceBytes);
+    /* utils::customAllReduceUtils::getMaxRequiredWorkspaceSize (common/customAllReduceUtils.h:30-37) */
+    size_t mi355q_allreduce_max_workspace_size(int32_t worldSize);
+
+#define MI355Q_MAX_RANKS_PER_NODE 8 /* kernels/customAllReduceKernels.h:33 */
+#define MI355Q_IPC_HANDLE_BYTES 64  /* sizeof(hipIpcMemHandle_t) */
+    /* kernels/customAllReduceKernels.h:44-58 AllReduceParams (+ timeout_flag: the flag spins are bounded here; a
+     * device word that receives 1 when a peer never arrived, or NULL) */
+    typedef struct
+    {
+        size_t elts_total;
+        size_t elts_per_rank;
+        size_t elts_per_block;
+        size_t rank_offset;
+        size_t ranks_per_node, rank, local_rank;
+        uint32_t barrier_flag;
+        uint32_t* peer_barrier_ptrs_in[MI355Q_MAX_RANKS_PER_NODE];
+        uint32_t* peer_barrier_ptrs_out[MI355Q_MAX_RANKS_PER_NODE];
+        void* peer_comm_buffer_ptrs[MI355Q_MAX_RANKS_PER_NODE];
+        void* local_output_buffer_ptr;
+        uint32_t* timeout_flag;
+    } mi355q_allreduce_params;
+    /* AllReduceParams::deserialize(buffer, tpSize, tpRank, flag_value) (customAllReduceKernels.cu:398-425):
+     * buffer_ptrs = HOST array [4 * tpSize]: ping buffers | pong buffers | barrier-in | barrier-out, one per rank */
+    mi355q_status mi355q_allreduce_params_deserialize(mi355q_allreduce_params* out, const void* const* buffer_ptrs,
+        size_t tpSize, size_t tpRank, uint32_t flag_value);
+    /* customAllReduce(params, data, elts, size_per_elem, dataType, strat, stream) (:427-454): one-shot / two-shot sum
+     * over the peers' comm buffers into `data`; the caller has copied its input into peer_comm_buffer_ptrs[rank]
+     * (allreducePlugin.cpp:195-199).  dtype MI355Q_FLOAT / HALF / BF16; strategy MI355Q_AR_ONESHOT / TWOSHOT. */
+    mi355q_status mi355q_custom_all_reduce(mi355q_allreduce_params* params, void* data, size_t elts, int32_t dtype,
+        int32_t strategy, void* stream);
+    /* invokeMultiGpuBarrier (:391-394) over peer_barrier_ptrs_out */
+    mi355q_status mi355q_multi_gpu_barrier(const mi355q_allreduce_params* params, void* stream);
+    /* IpcMemory (tensorrt_llm/_ipc_utils.py:66-133; cpp/tensorrt_llm/runtime/ipcUtils.cpp): set-up time helpers --
+     * allocate a zeroed fine-grained device buffer, export / import it across the ranks' processes.  These are the
+     * only entry points that allocate device memory. */
+    mi355q_status mi355q_ipc_alloc(size_t bytes, void** ptr);
+    mi355q_status mi355q_ipc_free(void* ptr);
+    mi355q_status mi355q_ipc_get_handle(void* ptr, uint8_t handle[MI355Q_IPC_HANDLE_BYTES]);
+    mi355q_status mi355q_ipc_open_handle(const uint8_t handle[MI355Q_IPC_HANDLE_BYTES], void** ptr);
+    mi355q_status mi355q_ipc_close_handle(void* ptr);
 
 #ifdef __cplusplus
 }

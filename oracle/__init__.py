@@ -540,3 +540,29 @@ def norm_quant(x, gamma, beta, eps, kind="rms", scale=None, dynamic=False, use_d
     if scale is not None:
         return cast_int8_rni_sat(val.float() * np.float32(scale)).reshape(x.shape), None
     return val.reshape(x.shape), None
+
+
+# ----------------------------------------------------------------------------- custom all-reduce
+def _add_T(a, b):
+    """One add in T arithmetic: fp32 add of the widened operands, one rounding to T (half2 / bfloat162 add)."""
+    return (a.float() + b.float()).to(a.dtype)
+
+
+def custom_all_reduce(inputs, rank, strategy="oneshot"):
+    """What rank `rank` receives from the one-shot / two-shot kernels (customAllReduceKernels.cu:137-291):
+    sums start from +0 and add the ranks' values in the order (owner + i) % N, every add rounded to T, where the
+    owner is `rank` itself for one-shot and, for two-shot, the rank that owns the element's slice
+    (slice r = elements [r * n/N, (r+1) * n/N))."""
+    N = len(inputs)
+    n = inputs[0].numel()
+    flat = [x.reshape(-1) for x in inputs]
+
+    def ordered_sum(owner, lo, hi):
+        acc = torch.zeros(hi - lo, dtype=inputs[0].dtype)
+        for i in range(N):
+            acc = _add_T(acc, flat[(owner + i) % N][lo:hi])
+        return acc
+    if strategy == "oneshot":
+        return ordered_sum(rank, 0, n).reshape(inputs[0].shape)
+    per = n // N
+    return torch.cat([ordered_sum(r, r * per, (r + 1) * per) for r in range(N)]).reshape(inputs[0].shape)

@@ -55,6 +55,17 @@ void layer_norm(void* out, const void* input, const void* gamma, const void* bet
     bool use_diff_of_squares, const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream);
 void quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scale, int type, hipStream_t stream);
 
+// allreduce.hip
+void allreduce_params_deserialize(
+    mi355q_allreduce_params& out, const void* const* buffer_ptrs, size_t tpSize, size_t tpRank, uint32_t flag_value);
+void custom_all_reduce(mi355q_allreduce_params& params, void* data, size_t elts, int dtype, int strat, hipStream_t stream);
+void multi_gpu_barrier_launch(const mi355q_allreduce_params& params, hipStream_t stream);
+void ipc_alloc(size_t bytes, void** ptr);
+void ipc_free(void* ptr);
+void ipc_get_handle(void* ptr, uint8_t* handle);
+void ipc_open_handle(const uint8_t* handle, void** ptr);
+void ipc_close_handle(void* ptr);
+
 // decode_attn.hip
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q);
 void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream);

@@ -635,6 +635,95 @@ struct NormQuantizationPlugin : PluginBase
     }
 };
 
+// ===================================================================== AllReduce
+// plugins/ncclPlugin/allreducePlugin.{h,cpp}: inputs: tensor (type_id); when strategy != RING a HOST int64 tensor
+// [4 * tp_size] of peer pointers (ping | pong | barrier-in | barrier-out, CustomAllReduceHelper.allocate_workspace,
+// tensorrt_llm/plugin/plugin.py:386-403).  Output: the summed tensor.
+struct AllReducePlugin : PluginBase
+{
+    std::vector<int32_t> mGroup;
+    int32_t mType;
+    int8_t mStrategy;
+    int32_t mCounter;
+    int32_t mRank; // this process's rank inside the group; -1 = $RANK % nRanks at enqueue (the reference asks MPI)
+    AllReducePlugin(std::vector<int32_t> group, int type, int strategy, int counter, int rank)
+        : mGroup(std::move(group))
+        , mType(type)
+        , mStrategy((int8_t) strategy)
+        , mCounter(counter)
+        , mRank(rank)
+    {
+        MQ_CHECK(mStrategy >= MI355Q_AR_RING && mStrategy <= MI355Q_AR_AUTO, "strategy %d", (int) mStrategy);
+        if (mType != MI355Q_FLOAT && mType != MI355Q_HALF && mType != MI355Q_BF16)
+            MQ_UNSUPPORTED("AllReduce: unsupported data type %d", mType);
+    }
+    const char* type() const override
+    {
+        return "AllReduce";
+    }
+    PluginBase* clone() const override
+    {
+        return new AllReducePlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int, mi355q_dims* out) const override // :76-80
+    {
+        MQ_CHECK(idx == 0, "outputIndex %d", idx);
+        *out = in[0];
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int) const override // :82-98
+    {
+        if (mStrategy != MI355Q_AR_RING && pos == 1 && nbIn == 2)
+            return io[pos].type == MI355Q_INT64 && io[pos].format == 0;
+        return io[pos].type == mType && io[pos].format == 0;
+    }
+    int getOutputDataType(int idx, const int32_t* inTypes, int) const override
+    {
+        MQ_CHECK(idx == 0, "index %d", idx);
+        return inTypes[0];
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override // :141-203
+    {
+        const int64_t size = dims_prod(inDesc[0].dims, 0, inDesc[0].dims.nbDims);
+        const size_t sizePerElem = dtype_size(mType);
+        int runtimeStrategy = mStrategy;
+        if (runtimeStrategy == MI355Q_AR_AUTO)
+            runtimeStrategy = mi355q_allreduce_select_implementation(
+                size * sizePerElem, (int) mGroup.size(), mi355q_allreduce_max_workspace_size((int) mGroup.size()));
+        if (runtimeStrategy == MI355Q_AR_RING)
+            MQ_UNSUPPORTED(
+                "AllReduce: the RING strategy is RCCL's all-reduce, issued by the host side (torch.distributed, "
+                "mi355q/tp.py all_reduce_sum); this plugin runs ONESHOT / TWOSHOT");
+        const int nRanks = inDesc[1].dims.d[0] / 4; // NUM_POINTERS_PER_RANK
+        MQ_CHECK(nRanks >= 2 && inDesc[1].dims.d[0] == 4 * nRanks, "all_reduce_workspace length %d", inDesc[1].dims.d[0]);
+        int myRank = mRank;
+        if (myRank < 0)
+        {
+            const char* e = getenv("RANK");
+            MQ_CHECK(e, "AllReduce: no 'rank' field and no RANK in the environment");
+            myRank = atoi(e);
+        }
+        myRank %= nRanks;
+        mi355q_allreduce_params params;
+        allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, mCounter);
+        MQ_HIP(hipMemcpyAsync(
+            params.peer_comm_buffer_ptrs[myRank], inputs[0], size * sizePerElem, hipMemcpyDeviceToDevice, stream));
+        custom_all_reduce(params, outputs[0], size, mType, runtimeStrategy, stream);
+    }
+    size_t serializationSize() const override // :268-284
+    {
+        return sizeof(int32_t) + sizeof(int8_t) + sizeof(int32_t) + sizeof(int32_t) * mGroup.size();
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mType);
+        write(buf, mStrategy);
+        write(buf, mCounter);
+        for (int32_t g : mGroup)
+            write(buf, g);
+    }
+};
+
 // ===================================================================== Fp8Gemm (no reference plugin)
 // inputs: 0 A e4m3 [.., K]; 1 B e4m3 [N, K]; 2 scale_a fp32 [1]; 3 scale_b fp32 [1]
 struct Fp8GemmPlugin : PluginBase
@@ -1104,7 +1193,7 @@ GptAttentionFields parse_attention_fields(const FieldReader& r) // gptAttentionP
 
 const char* const kPluginNames[] = {"WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
     "QuantizePerToken", "GPTAttention", "Fp8Gemm", "QuantizeTensor", "RmsnormQuantization", "LayernormQuantization",
-    nullptr};
+    "AllReduce", nullptr};
 
 PluginBase* create_plugin(const char* name, const FieldReader& r)
 {
@@ -1128,6 +1217,14 @@ PluginBase* create_plugin(const char* name, const FieldReader& r)
         return new Fp8GemmPlugin(r.req_int("type_id"));
     if (n == "QuantizeTensor")
         return new QuantizeTensorPlugin();
+    if (n == "AllReduce") // createPlugin, allreducePlugin.cpp:306-350
+    {
+        const mi355q_plugin_field* g = r.find("group");
+        MQ_CHECK(g && g->type == MI355Q_FIELD_INT32 && g->length > 0, "AllReduce: field 'group' (int32 list) is missing");
+        const int32_t* gi = static_cast<const int32_t*>(g->data);
+        return new AllReducePlugin(std::vector<int32_t>(gi, gi + g->length), r.req_int("type_id"),
+            r.opt_int("strategy", MI355Q_AR_AUTO), r.opt_int("counter", 0), r.opt_int("rank", -1));
+    }
     if (n == "RmsnormQuantization") // createPlugin, rmsnormQuantizationPlugin.cpp:253-290
         return new NormQuantizationPlugin(
             false, r.opt_float("eps", 1e-5f), false, r.req_int("dyn_act_scaling") != 0, r.req_int("type_id"));
@@ -1205,6 +1302,19 @@ PluginBase* deserialize_plugin(const char* name, const void* data, size_t length
     {
         need(0);
         out = new QuantizeTensorPlugin();
+    }
+    else if (n == "AllReduce") // allreducePlugin.cpp:42-62: type, strategy, counter, then the group to the end
+    {
+        MQ_CHECK(length >= 9 && (length - 9) % 4 == 0, "Expected length (%d) != real length", (int) length);
+        int32_t t, c;
+        int8_t st;
+        read(d, t);
+        read(d, st);
+        read(d, c);
+        std::vector<int32_t> group((length - 9) / 4);
+        for (auto& g : group)
+            read(d, g);
+        out = new AllReducePlugin(group, t, st, c, -1);
     }
     else if (n == "RmsnormQuantization" || n == "LayernormQuantization")
     {
@@ -1585,6 +1695,74 @@ extern "C"
                 MQ_CHECK(params, "null argument");
                 context_attention(*params, static_cast<hipStream_t>(stream));
             });
+    }
+
+    size_t mi355q_allreduce_max_workspace_size(int32_t worldSize)
+    {
+        return worldSize <= 2 ? 16 * 1000 * 1000 : 8 * 1000 * 1000;
+    }
+
+    mi355q_status mi355q_allreduce_params_deserialize(mi355q_allreduce_params* out, const void* const* buffer_ptrs,
+        size_t tpSize, size_t tpRank, uint32_t flag_value)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(out, "null argument");
+                allreduce_params_deserialize(*out, buffer_ptrs, tpSize, tpRank, flag_value);
+            });
+    }
+
+    mi355q_status mi355q_custom_all_reduce(mi355q_allreduce_params* params, void* data, size_t elts, int32_t dtype,
+        int32_t strategy, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                custom_all_reduce(*params, data, elts, dtype, strategy, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_multi_gpu_barrier(const mi355q_allreduce_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                multi_gpu_barrier_launch(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_ipc_alloc(size_t bytes, void** ptr)
+    {
+        return guarded([&] { ipc_alloc(bytes, ptr); });
+    }
+    mi355q_status mi355q_ipc_free(void* ptr)
+    {
+        return guarded([&] { ipc_free(ptr); });
+    }
+    mi355q_status mi355q_ipc_get_handle(void* ptr, uint8_t handle[MI355Q_IPC_HANDLE_BYTES])
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(ptr && handle, "null argument");
+                ipc_get_handle(ptr, handle);
+            });
+    }
+    mi355q_status mi355q_ipc_open_handle(const uint8_t handle[MI355Q_IPC_HANDLE_BYTES], void** ptr)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(ptr && handle, "null argument");
+                ipc_open_handle(handle, ptr);
+            });
+    }
+    mi355q_status mi355q_ipc_close_handle(void* ptr)
+    {
+        return guarded([&] { ipc_close_handle(ptr); });
     }
 
     // AllreducePlugin::selectImplementation, plugins/ncclPlugin/allreducePlugin.cpp:111-139

@@ -96,6 +96,22 @@ class ContextAttentionParams(C.Structure):
     ]
 
 
+MAX_RANKS_PER_NODE, IPC_HANDLE_BYTES = 8, 64
+AR_RING, AR_ONESHOT, AR_TWOSHOT, AR_AUTO = range(4)
+
+
+class AllReduceParams(C.Structure):
+    _fields_ = [
+        ("elts_total", C.c_size_t), ("elts_per_rank", C.c_size_t), ("elts_per_block", C.c_size_t),
+        ("rank_offset", C.c_size_t), ("ranks_per_node", C.c_size_t), ("rank", C.c_size_t), ("local_rank", C.c_size_t),
+        ("barrier_flag", C.c_uint32),
+        ("peer_barrier_ptrs_in", C.c_void_p * MAX_RANKS_PER_NODE),
+        ("peer_barrier_ptrs_out", C.c_void_p * MAX_RANKS_PER_NODE),
+        ("peer_comm_buffer_ptrs", C.c_void_p * MAX_RANKS_PER_NODE),
+        ("local_output_buffer_ptr", C.c_void_p), ("timeout_flag", C.c_void_p),
+    ]
+
+
 class Mi355qError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"mi355q status {status}: {msg}")
@@ -146,6 +162,15 @@ SYMBOLS = {
     "mi355q_context_attention_workspace_size": (_sz, [C.POINTER(ContextAttentionParams)]),
     "mi355q_context_attention": (_i32, [C.POINTER(ContextAttentionParams), _vp]),
     "mi355q_allreduce_select_implementation": (_i32, [_sz, _i32, _sz]),
+    "mi355q_allreduce_max_workspace_size": (_sz, [_i32]),
+    "mi355q_allreduce_params_deserialize": (_i32, [C.POINTER(AllReduceParams), _PP, _sz, _sz, C.c_uint32]),
+    "mi355q_custom_all_reduce": (_i32, [C.POINTER(AllReduceParams), _vp, _sz, _i32, _i32, _vp]),
+    "mi355q_multi_gpu_barrier": (_i32, [C.POINTER(AllReduceParams), _vp]),
+    "mi355q_ipc_alloc": (_i32, [_sz, _PP]),
+    "mi355q_ipc_free": (_i32, [_vp]),
+    "mi355q_ipc_get_handle": (_i32, [_vp, _vp]),
+    "mi355q_ipc_open_handle": (_i32, [_vp, _PP]),
+    "mi355q_ipc_close_handle": (_i32, [_vp]),
 }
 
 

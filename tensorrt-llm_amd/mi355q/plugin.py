@@ -46,13 +46,13 @@ def _field_array(fields):
     np_t = {L.FIELD_INT8: np.int8, L.FIELD_INT16: np.int16, L.FIELD_INT32: np.int32,
             L.FIELD_FLOAT32: np.float32, L.FIELD_FLOAT64: np.float64}
     for i, (name, value, ftype) in enumerate(fields):
-        buf = np.array([value], dtype=np_t[ftype])
+        buf = np.array(list(value) if isinstance(value, (list, tuple)) else [value], dtype=np_t[ftype])
         nm = name.encode()
         keep += [buf, nm]
         arr[i].name = nm
         arr[i].data = buf.ctypes.data
         arr[i].type = ftype
-        arr[i].length = 1
+        arr[i].length = buf.size
     return arr, keep
 
 

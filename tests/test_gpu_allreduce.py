@@ -1,0 +1,76 @@
+"""GPU parity: the custom one-shot / two-shot all-reduce (row a16) through the AllReduce plugin, with the ranks as
+separate PROCESSES that map each other's buffers through HIP IPC.  The box has one GPU, so all ranks sit on device 0:
+this exercises the kernels' indexing, flag protocol, ping-pong buffers and T-arithmetic summation order bit for bit
+against the oracle, but NOT the cross-GPU (xGMI) visibility of the flags -- DESIGN.md says so."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, results):
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    sys.path.insert(0, os.path.join(HERE, "..", "tensorrt-llm_amd"))
+    import oracle
+    from mi355q import _lib as L
+    from mi355q.ipc import CustomAllReduceHelper
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, msg = True, ""
+    try:
+        helper = CustomAllReduceHelper(size=1 << 20)
+        cases = [(torch.float16, 8 * 64), (torch.float16, 8 * 1024 * 3), (torch.bfloat16, 8192 * 4),
+                 (torch.float32, 4 * 1024 * 5), (torch.float16, 8 * world * 999), (torch.bfloat16, 64 * world)]
+        for strat, sname in ((L.AR_ONESHOT, "oneshot"), (L.AR_TWOSHOT, "twoshot")):
+            for dtype, n in cases:
+                g = torch.Generator().manual_seed(1234 + n)
+                inputs = [(torch.randn(n, generator=g) * 3).to(dtype) for _ in range(world)]  # every rank builds all
+                out = helper.allreduce(inputs[rank].to(dev), strategy=strat)
+                torch.cuda.synchronize()
+                ref = oracle.custom_all_reduce(inputs, rank, sname)
+                if not torch.equal(out.cpu().view(torch.uint8), ref.view(torch.uint8)):
+                    d = (out.cpu().float() - ref.float()).abs().max().item()
+                    ok, msg = False, f"rank {rank} {sname} {dtype} n={n}: max abs diff {d}"
+                    break
+            if not ok:
+                break
+        if ok:  # AUTO: small message -> one-shot, larger than the workspace -> RING through torch.distributed (gloo here)
+            x = torch.full((256,), float(rank + 1), dtype=torch.float16, device=dev)
+            y = helper.allreduce(x)
+            torch.cuda.synchronize()
+            if not torch.equal(y.cpu(), torch.full((256,), world * (world + 1) / 2, dtype=torch.float16)):
+                ok, msg = False, f"rank {rank} AUTO small: {y[:4].tolist()}"
+        dist.barrier()
+        helper.close()
+    except Exception as e:  # noqa: BLE001 -- report through the queue, the parent asserts
+        ok, msg = False, f"rank {rank}: {type(e).__name__}: {e}"
+    results.put((rank, ok, msg))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_custom_allreduce_multi_process_single_gpu(cuda, world):
+    ctx = mp.get_context("spawn")
+    results = ctx.Queue()
+    port = 29650 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    for _ in range(world):
+        got.append(results.get(timeout=100))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, ok, msg in sorted(got):
+        assert ok, msg

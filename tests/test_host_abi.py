@@ -230,6 +230,34 @@ def test_feeder_plugins_shapes_formats_and_serialization():
     assert qt.get_output_data_type(0, [L.HALF, L.FLOAT]) == L.INT8 and qt.serialize() == b""
 
 
+def test_allreduce_plugin_fields_serialization_and_deserialize_params():
+    plg = Plugin("AllReduce", [("group", [0, 1, 2, 3], L.FIELD_INT32), ("type_id", L.HALF, L.FIELD_INT32),
+                               ("strategy", L.AR_ONESHOT, L.FIELD_INT8), ("counter", 7, L.FIELD_INT32)])
+    blob = plg.serialize()  # int32 type, int8 strategy, int32 counter, int32 group[...] (allreducePlugin.cpp:268-284)
+    assert len(blob) == 4 + 1 + 4 + 16 and blob[4] == L.AR_ONESHOT
+    assert np.frombuffer(blob[9:], np.int32).tolist() == [0, 1, 2, 3]
+    assert Plugin.deserialize("AllReduce", blob).serialize() == blob
+    assert plg.get_output_dimensions(0, [[5, 8192], [16]]) == [5, 8192]
+    # RING is the host's RCCL call: the plugin says so instead of running something else
+    ring = Plugin("AllReduce", [("group", [0, 1], L.FIELD_INT32), ("type_id", L.HALF, L.FIELD_INT32),
+                                ("strategy", L.AR_RING, L.FIELD_INT8), ("counter", 0, L.FIELD_INT32)])
+    with pytest.raises(L.Mi355qError, match="RING"):
+        ring.enqueue([torch.zeros(8, dtype=torch.float16)], [torch.zeros(8, dtype=torch.float16)])
+    # AllReduceParams::deserialize: even flags use the ping buffers, odd the pong buffers
+    import ctypes as C
+    tp = 4
+    table = (C.c_void_p * (4 * tp))(*[0x1000 * (i + 1) for i in range(4 * tp)])
+    prm = L.AllReduceParams()
+    L.check(L.lib().mi355q_allreduce_params_deserialize(C.byref(prm), table, tp, 2, 6))
+    assert [prm.peer_comm_buffer_ptrs[i] for i in range(tp)] == [0x1000 * (i + 1) for i in range(tp)]
+    assert prm.peer_barrier_ptrs_in[0] == 0x1000 * (2 * tp + 1) and prm.peer_barrier_ptrs_out[3] == 0x1000 * (4 * tp)
+    assert (prm.ranks_per_node, prm.rank, prm.local_rank, prm.barrier_flag) == (4, 2, 2, 6)
+    L.check(L.lib().mi355q_allreduce_params_deserialize(C.byref(prm), table, tp, 1, 7))
+    assert prm.peer_comm_buffer_ptrs[0] == 0x1000 * (tp + 1)
+    assert L.lib().mi355q_allreduce_max_workspace_size(2) == 16_000_000
+    assert L.lib().mi355q_allreduce_max_workspace_size(8) == 8_000_000
+
+
 def test_allreduce_strategy_selection_matches_reference():
     # plugins/ncclPlugin/allreducePlugin.cpp:111-139
     sel = L.lib().mi355q_allreduce_select_implementation
