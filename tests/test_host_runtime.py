@@ -1,0 +1,145 @@
+"""CPU tests of the host-side pieces either side of the kernels: the paged-KV block manager
+(mirror of tensorrt_llm/runtime/kv_cache_manager.py) and the GPTQ / AWQ checkpoint-tensor conversions
+(tensorrt_llm/models/llama/weight.py).  The layout transform they call is the C ABI's host routine."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from mi355q import _lib as L
+from mi355q import checkpoint as ck
+from mi355q import functional as F
+from mi355q.kv_cache_manager import BlocksManager, GenerationSequence, KVCacheManager
+
+
+def make_pools(layers, blocks, tpb, heads=2, dh=8, dtype=torch.float16):
+    return [torch.zeros(2 * blocks * heads * tpb * dh, dtype=dtype) for _ in range(layers)]
+
+
+def test_blocks_manager_pointer_layout_and_reuse():
+    blocks, tpb = 6, 4
+    pools = make_pools(2, blocks, tpb)
+    bm = BlocksManager(pools, blocks, max_blocks_per_seq=3)
+    epb = pools[0].nelement() // (2 * blocks)
+    s0, s1 = GenerationSequence(10, 0), GenerationSequence(11, 1)
+    bm.allocate(s0)
+    bm.allocate(s1)
+    bm.allocate(s0)
+    arr = bm.get_pointer_array(1, 1)
+    assert arr.shape == (2, 1, 2, 3) and arr.dtype == torch.int64
+    base = pools[1].data_ptr()
+    assert arr[0, 0, 0].tolist() == [base, base + 2 * epb * 2, 0]              # blocks 0 and 2 (FIFO order)
+    assert arr[1, 0, 0].tolist() == [base + 1 * epb * 2, 0, 0]
+    assert arr[0, 0, 1, 0].item() == base + (blocks + 0) * epb * 2             # V half follows all K blocks
+    assert bm.get_number_blocks(s0) == 2
+    bm.free(s0)
+    assert len(bm.free_blocks) == 5 and [b.idx for b in bm.free_blocks] == [3, 4, 5, 0, 2]
+    for _ in range(5):
+        bm.allocate(s1)
+    with pytest.raises(RuntimeError, match="Can't allocate new block"):
+        bm.allocate(s1)
+
+
+def test_kv_cache_manager_context_and_steps():
+    blocks, tpb, max_blocks = 16, 4, 4
+    pools = make_pools(3, blocks, tpb)
+    mgr = KVCacheManager(pools, blocks, tpb, max_blocks, max_attention_window_size=16, sink_token_len=0)
+    a, b = GenerationSequence(0, 0), GenerationSequence(1, 1)
+    mgr.add_sequence(a, context_len=5)    # 2 blocks
+    mgr.add_sequence(b, context_len=8)    # exactly 2 blocks: the 9th token opens a third at the first step
+    assert mgr.blocks_manager.get_number_blocks(a) == 2 and mgr.blocks_manager.get_number_blocks(b) == 2
+    ptrs = mgr.get_block_pointers(1)
+    assert ptrs.shape == (3, 2, 1, 2, max_blocks)
+    mgr.step([False, False])
+    assert mgr.blocks_manager.get_number_blocks(a) == 2 and mgr.blocks_manager.get_number_blocks(b) == 3
+    assert mgr.lens == [6, 9]
+    for _ in range(2):
+        mgr.step([False, False])
+    mgr.step([False, False])              # a: length 8 -> token 9 starts block 3
+    assert mgr.blocks_manager.get_number_blocks(a) == 3
+    mgr.step([True, False])               # a finishes: its blocks return, b becomes batch index 0
+    assert len(mgr.sequences) == 1 and mgr.sequences[0].get_batch_idx() == 0 and mgr.lens == [13]
+    assert len(mgr.blocks_manager.free_blocks) == blocks - mgr.blocks_manager.get_number_blocks(b)
+    # cyclic window: once the window is full no further blocks are taken
+    for _ in range(10):
+        mgr.step([False])
+    assert mgr.blocks_manager.get_number_blocks(b) == 4 == max_blocks
+
+
+def test_kv_cache_manager_sink_bubble_and_beams():
+    pools = make_pools(1, 32, 4)
+    mgr = KVCacheManager(pools, 32, 4, 8, max_attention_window_size=16, sink_token_len=2, beam_width=2)
+    assert mgr.bubble_len == 2 and mgr.sink_block_token_num == 4 and mgr.max_token_num == 18
+    s = GenerationSequence(7, 0)
+    mgr.add_sequence(s, context_len=5)    # 5 + bubble 2 = 7 tokens -> 2 blocks, the last one not shared across beams
+    beams = mgr.blocks_manager.allocated_blocks[s]
+    assert beams[0][0] is beams[1][0] and beams[0][0].is_shared()
+    assert beams[0][1] is not beams[1][1]
+    ptr = mgr.get_block_pointers(2)
+    assert ptr.shape == (1, 1, 2, 2, 8) and ptr[0, 0, 0, 0, 0] == ptr[0, 0, 1, 0, 0] and ptr[0, 0, 0, 0, 1] != ptr[0, 0, 1, 0, 1]
+
+
+def _gptq_pack(q_u4_kn, z_u4, ):
+    k, n = q_u4_kn.shape
+    qw = torch.zeros(k // 8, n, dtype=torch.int32)
+    for i in range(8):
+        qw |= q_u4_kn[i::8].to(torch.int32) << (4 * i)
+    g, _ = z_u4.shape
+    qz = torch.zeros(g, n // 8, dtype=torch.int32)
+    for i in range(8):
+        qz |= z_u4[:, i::8].to(torch.int32) << (4 * i)
+    return qw, qz
+
+
+def test_gptq_tensors_to_plugin_tensors():
+    # a GPTQ checkpoint's dequantisation is scale * (q - (z + 1)); the converted tensors must dequantise to the same
+    g0 = torch.Generator().manual_seed(0)
+    k, n, gs = 256, 128, 64
+    q = torch.randint(0, 16, (k, n), generator=g0)
+    z = torch.randint(0, 15, (k // gs, n), generator=g0)
+    scales = (torch.rand(k // gs, n, generator=g0) * 0.02 + 0.005).half()
+    qw, qz = _gptq_pack(q, z)
+    t = ck.gptq_to_tllm(qw, qz, scales, layout=L.LAYOUT_ROW_MAJOR)
+    assert t["weight"].shape == (k, n // 2) and t["weight"].dtype == torch.int8
+    unpacked = F.unpack_int4_packed_tensor_to_int8(t["weight"])          # signed int4 values, [K, N]
+    assert torch.equal(unpacked.to(torch.int64), q - 8)
+    want_zero = ((-(z) + 8 - 1).half() * scales)
+    assert torch.equal(t["zero"], want_zero)
+    deq = oracle.dequant_fma(unpacked, t["weights_scaling_factor"], t["zero"], gs).float()
+    ref = (scales.float().repeat_interleave(gs, 0) * (q - (z.repeat_interleave(gs, 0) + 1)).float())
+    assert (deq - ref).abs().max().item() <= 2e-3                         # one fp16 rounding of the zero term
+    # the production layout is the same values behind the GFX950 permutation
+    t2 = ck.gptq_to_tllm(qw, qz, scales)
+    back = F.unprocess_weights_for_mixed_gemm(t2["weight"], torch.quint4x2, L.LAYOUT_GFX950)
+    assert torch.equal(back, t["weight"])
+    # TP: column split (dim 1) of every tensor
+    t_r1 = ck.gptq_to_tllm(qw, qz, scales, tp_size=2, tp_rank=1, tp_dim=1, layout=L.LAYOUT_ROW_MAJOR)
+    assert torch.equal(F.unpack_int4_packed_tensor_to_int8(t_r1["weight"]), unpacked[:, n // 2:])
+    assert torch.equal(t_r1["zero"], want_zero[:, n // 2:])
+
+
+def test_awq_tensors_to_plugin_tensors():
+    g0 = torch.Generator().manual_seed(1)
+    n, k, gs = 64, 256, 128
+    w = torch.randn(n, k, generator=g0)
+    amax = w.reshape(n, k // gs, gs).abs().amax(-1).reshape(-1)           # AMMO stores amax per (n, group)
+    pqs = torch.rand(k, generator=g0) + 0.5
+    t = ck.awq_to_tllm(w, amax, pqs, gs, layout=L.LAYOUT_ROW_MAJOR)
+    scale = t["weights_scaling_factor"]
+    assert scale.shape == (k // gs, n) and t["prequant_scaling_factor"].shape == (1, k)
+    q = F.unpack_int4_packed_tensor_to_int8(t["weight"]).float()
+    assert q.min().item() >= -8 and q.max().item() <= 7
+    deq = q * (amax.reshape(n, k // gs).T / 8.0).repeat_interleave(gs, 0)
+    # half a step everywhere, a whole step where +amax rounds to 8 and is clamped to 7
+    assert (deq - w.T).abs().max().item() <= amax.max().item() / 8.0 + 1e-6
+    # row-parallel split (tp_dim 0) also splits the pre-quant scale
+    t1 = ck.awq_to_tllm(w, amax, pqs, gs, tp_size=2, tp_rank=1, tp_dim=0, layout=L.LAYOUT_ROW_MAJOR)
+    assert t1["weight"].shape == (k // 2, n // 2) and torch.equal(t1["prequant_scaling_factor"],
+                                                                  t["prequant_scaling_factor"][:, k // 2:])
+    # qkv fusion: re-smoothing to the averaged pre-quant scale keeps (x * s_avg) @ w' == (x * s) @ w
+    w_kn = w.T.contiguous()
+    avg = (pqs + 0.25)
+    w2, sc2 = ck.resmooth_and_get_scale(w_kn, pqs.reshape(1, k), avg.reshape(1, k), gs)
+    x = torch.randn(3, k, generator=g0)
+    assert torch.allclose((x * avg) @ w2, (x * pqs) @ w_kn, rtol=1e-4, atol=1e-4)
+    assert sc2.shape == (k // gs, n)
