@@ -56,6 +56,57 @@ def build_attention_case(dev, B=64, H=32, D=128, ctx=2048, tpb=64, seed=42):
     return plg, inputs, out, ws, algo_bytes, keep
 
 
+def bench_decode_attention(dev, steps, B=64, Hq=8, Hkv=1, D=128, ctx=2048, tpb=64, kv="int8", ragged=False, sets=1):
+    """Other decode-attention configs of the metric family: cfg4 (Llama-2-70B TP=8 per-GPU slice: 8 q heads on one
+    int8 kv head), cfg5 (fp8 KV, 32 q / 8 kv heads), GQA bf16, and cfg2's ragged variant (lengths in [1024, 2048]).
+    `sets` independent caches are cycled when one step's K/V would fit the 256 MB Infinity Cache."""
+    from mi355q import functional as F
+    g = torch.Generator(device="cpu").manual_seed(7)
+    kvdt = {"bf16": torch.bfloat16, "int8": torch.int8, "fp8": torch.float8_e4m3fn}[kv]
+    esz = 2 if kv == "bf16" else 1
+    nblk = B * (ctx // tpb)
+    lens = torch.randint(1024, ctx + 1, (B,), generator=g, dtype=torch.int32) if ragged else torch.full((B,), ctx, dtype=torch.int32)
+    cases = []
+    for _ in range(sets):
+        if kv == "bf16":
+            pool = (torch.randn(nblk, 2, Hkv, tpb, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        elif kv == "int8":
+            pool = torch.randint(-127, 128, (nblk, 2, Hkv, tpb, D), generator=g, dtype=torch.int8).to(dev)
+        else:
+            pool = (torch.randn(nblk, 2, Hkv, tpb, D, generator=g) * 0.5).to(torch.float8_e4m3fn).to(dev)
+        perm = torch.randperm(nblk, generator=g).reshape(B, ctx // tpb)
+        be = Hkv * tpb * D * esz
+        ptrs = (torch.stack([perm * 2 * be, perm * 2 * be + be], 1) + pool.data_ptr()).reshape(1, B, 2, -1)
+        cases.append((pool, ptrs.to(dev), ptrs))
+    qkv = torch.randn(B, 1, (Hq + 2 * Hkv) * D, generator=g).to(torch.bfloat16).to(dev)
+    qm = {"bf16": 0, "int8": 1 << 6, "fp8": 1 << 7}[kv]
+    plg = F.make_gpt_attention_plugin(num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="bfloat16",
+                                      position_embedding_type=2, rotary_embedding_dim=D, tokens_per_block=tpb,
+                                      kv_cache_quant_mode=qm)
+    sc = [torch.tensor([32.0], device=dev), torch.tensor([1 / 32.0], device=dev)] if qm else []
+    out = torch.empty(B, 1, Hq * D, dtype=torch.bfloat16, device=dev)
+
+    def inputs_of(c):
+        return [qkv, lens.to(dev), lens - 1, torch.tensor([ctx], dtype=torch.int32), torch.zeros(1, dtype=torch.int32),
+                (lens - 1).to(dev), torch.zeros(B, 1, ctx, dtype=torch.int32, device=dev),
+                torch.ones(B, dtype=torch.int32), c[1], c[2]] + sc
+    ins = [inputs_of(c) for c in cases]
+    plg.configure(ins[0])
+    ws_bytes = plg.get_workspace_size(ins[0], [out])
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    it = [0]
+
+    def step():
+        plg.enqueue(ins[it[0] % sets], [out], ws)
+        it[0] += 1
+    _, dev_s = time_steps(step, steps, max(2, sets), lambda: None)
+    tok = int(lens.sum())
+    algo = 2 * Hkv * tok * D * esz + B * (Hq + 2 * Hkv) * D * 2 + B * Hq * D * 2 + 2 * B * Hkv * D * esz
+    return {"batch": B, "q_heads": Hq, "kv_heads": Hkv, "head_dim": D, "ctx": "1024..2048 ragged" if ragged else ctx,
+            "kv_cache": kv, "us_per_call": dev_s / steps * 1e6, "GBps": algo / (dev_s / steps) / 1e9,
+            "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo, "cache_sets": sets}
+
+
 def time_steps(fn, steps, warmup, barrier):
     for _ in range(warmup):
         fn()
@@ -353,6 +404,16 @@ def main():
                                      bench_gemv(dev, 2 * 72, m=1, n=4096, k=11008, sets=24),
                                      bench_gemv(dev, 48, m=1, n=28672, k=8192, sets=6),
                                      bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6)]
+                sec["decode_attention_other"] = [
+                    bench_decode_attention(dev, 48, Hq=32, Hkv=32, kv="bf16", ragged=True),          # cfg2 ragged
+                    bench_decode_attention(dev, 96, Hq=8, Hkv=1, kv="int8", sets=12),                 # cfg4 per-GPU slice
+                    bench_decode_attention(dev, 48, Hq=32, Hkv=8, kv="fp8", sets=2),                  # cfg5 fp8 KV
+                    bench_decode_attention(dev, 48, Hq=64, Hkv=8, kv="bf16"),                         # 70B GQA, bf16 KV
+                    bench_decode_attention(dev, 48, Hq=64, Hkv=8, kv="int8", sets=2)]                 # 70B GQA, int8 KV
+                sec["w4a16_gemm_tp8"] = [bench_gemv(dev, 144, m=mm, n=nn, k=kk, sets=ss)                # cfg4 per-GPU GEMMs
+                                         for (mm, nn, kk, ss) in ((1, 1280, 8192, 64), (1, 3584, 8192, 24),
+                                                                  (1, 8192, 1024, 72), (1, 8192, 3584, 24),
+                                                                  (8, 3584, 8192, 24), (64, 3584, 8192, 24))]
                 sec["int8_gemm"] = [bench_int8_gemm(dev, 10), bench_int8_gemm(dev, 10, n=5120, k=13824)]
                 sec["fp8_gemm"] = [bench_fp8_gemm(dev, 10), bench_fp8_gemm(dev, 10, n=4096, k=14336)]
                 sec["rmsnorm_quant"] = [bench_rmsnorm_quant(dev, 96), bench_rmsnorm_quant(dev, 96, hidden=8192, sets=16)]

@@ -83,33 +83,46 @@ __device__ __forceinline__ f32x4_t gemv_step(const uint4& w, const uint4& av, fl
 // not rounded to 16 bits before the multiply, so results differ from the exact-dequant path by
 // about half an output ulp (closer to the real-number result); mi355q_weight_only_dequantize and
 // the prefill GEMM keep the bit-exact rounding.
-template <typename T, int NSZ, int STEPS, typename AF>
-__device__ __forceinline__ void gemv_tile_int4(const uint4& w, f32x4_t& acc, const float* s, const float* z, AF afrag)
+template <typename T, int NSZ, int STEPS, int MC, typename AF>
+__device__ __forceinline__ void gemv_tile_int4(const uint4& w, f32x4_t (&acc)[MC], const float* s, const float* z, AF afrag)
 {
     const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w);
     constexpr int PER = STEPS / NSZ; // k-steps per scale group
 #pragma unroll
     for (int h = 0; h < NSZ; ++h)
     {
-        f32x4_t P = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t P[MC], S1[MC];
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+        {
+            P[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            S1[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int st = h * PER; st < (h + 1) * PER; ++st)
         {
-            const uint4 av = afrag(st);
-            P = mfma16<T>(av, unpack8_u4<T>(wd[st]), P);
-            S1 = mfma16<T>(av, ones8<T>(), S1);
+            const auto u = unpack8_u4<T>(wd[st]); // unpacked once, used by every 16-row chunk of m
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc)
+            {
+                const uint4 av = afrag(mc, st);
+                P[mc] = mfma16<T>(av, u, P[mc]);
+                S1[mc] = mfma16<T>(av, ones8<T>(), S1[mc]);
+            }
         }
         const float zc = fmaf(-8.f, s[h], z[h]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            acc[r] = fmaf(zc, S1[r], fmaf(s[h], P[r], acc[r]));
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[mc][r] = fmaf(zc, S1[mc][r], fmaf(s[h], P[mc][r], acc[mc][r]));
     }
 }
 
-// `afrag(kt, st)` returns the activation fragment of k-step st of tile kt (LDS or global).
-template <typename T, int WBITS, int CH, int NSZ, typename AF>
+// `afrag(mc, kt, st)` returns the activation fragment of k-step st of tile kt for m-chunk mc (LDS).
+template <typename T, int WBITS, int CH, int NSZ, int MC, typename AF>
 __device__ __forceinline__ void gemv_compute_chunk(
-    const GemvChunk<CH, NSZ>& c, f32x4_t& acc, int kt0, int kt_end, int kt_last, AF afrag)
+    const GemvChunk<CH, NSZ>& c, f32x4_t (&acc)[MC], int kt0, int kt_end, int kt_last, AF afrag)
 {
 #pragma unroll
     for (int i = 0; i < CH; ++i)
@@ -127,11 +140,17 @@ __device__ __forceinline__ void gemv_compute_chunk(
             z[h] = T16<T>::to_float(c.z[i][h]);
         }
         if constexpr (WBITS == 4)
-            gemv_tile_int4<T, NSZ, 4>(c.w[i], acc, s, z, [&](int st) { return afrag(kt, st); });
+            gemv_tile_int4<T, NSZ, 4, MC>(c.w[i], acc, s, z, [&](int mc, int st) { return afrag(mc, kt, st); });
         else
         {
-            acc = gemv_step<T, 8, 0>(c.w[i], afrag(kt, 0), s[0], z[0], acc);
-            acc = gemv_step<T, 8, 1>(c.w[i], afrag(kt, 1), s[0], z[0], acc);
+            const auto w0 = dequant_step<T, 8, 0>(c.w[i], s[0], z[0]);
+            const auto w1 = dequant_step<T, 8, 1>(c.w[i], s[0], z[0]);
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc)
+            {
+                acc[mc] = mfma16<T>(afrag(mc, kt, 0), w0, acc[mc]);
+                acc[mc] = mfma16<T>(afrag(mc, kt, 1), w1, acc[mc]);
+            }
         }
     }
 }
@@ -143,20 +162,22 @@ __device__ __forceinline__ void gemv_compute_chunk(
 // runs ONE ping-pong load pipeline over the whole (n-block, chunk) sequence, so the next n-block's
 // weights are already in flight while the current one is reduced (LDS, one 16x16 tile per n-block)
 // and stored -- the HBM queue never drains between n-blocks.
-template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ>
+// MC = 16-row chunks of m handled by one block (1, 2, 4): for 16 < m <= 64 the weights are still streamed ONCE and
+// every unpacked fragment feeds MC MFMAs (the prefill GEMM's 2-barrier tile loop is latency-bound at these sizes).
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ, int MC>
 __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
     constexpr int KTILE = Geo<WBITS>::KTILE;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // red[NWAVES][64][4] floats, then A rows
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // red[MC][NWAVES][64][4] floats, then A rows
     float* red = reinterpret_cast<float*>(smem);
-    uint8_t* a_lds = smem + NWAVES * 64 * 4 * sizeof(float);
+    uint8_t* a_lds = smem + MC * NWAVES * 64 * 4 * sizeof(float);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * 16;
+    const int m0 = blockIdx.y * 16 * MC;
     const int kh = (lane >> 4) * 8;
-    const int rows = min(16, a.m - m0);
+    const int rows = min(16 * MC, a.m - m0);
     const int nblocks = a.n >> 4;
     const int nb_stride = gridDim.x;
 
@@ -189,7 +210,6 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     };
 
     // rows >= m are clamped to the last valid row: their MFMA output rows are computed, never stored
-    const int rloc = min(lane & 15, rows - 1);
     const int lds_stride = (k_hi - k_lo) * 2 + 32;
 
     GemvChunk<CH, NSZ> ca, cb;
@@ -218,11 +238,17 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         }
     }
     __syncthreads();
-    const uint8_t* a_lane = a_lds + rloc * lds_stride + (kh - k_lo) * 2;
-    auto afrag = [&](int kt, int st) -> uint4
-    { return *reinterpret_cast<const uint4*>(a_lane + (kt * KTILE + st * 32) * 2); };
+    const uint8_t* a_lane[MC];
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+        a_lane[mc] = a_lds + min(16 * mc + (lane & 15), rows - 1) * lds_stride + (kh - k_lo) * 2;
+    auto afrag = [&](int mc, int kt, int st) -> uint4
+    { return *reinterpret_cast<const uint4*>(a_lane[mc] + (kt * KTILE + st * 32) * 2); };
 
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[MC];
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+        acc[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // end of an n-block: (half tile,) cross-wave reduce, bias, store
     auto flush = [&](int nb)
@@ -238,25 +264,28 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
             const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
             const uint4 w = make_uint4(hw.x, hw.y, 0, 0);
             if constexpr (WBITS == 4)
-                gemv_tile_int4<T, 1, 2>(w, acc, &s, &z, [&](int st) { return afrag(a.ktiles, st); });
+                gemv_tile_int4<T, 1, 2, MC>(w, acc, &s, &z, [&](int mc, int st) { return afrag(mc, a.ktiles, st); });
         }
         __syncthreads(); // the previous n-block's readers are done with `red`
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-            red[(wave * 64 + lane) * 4 + r] = acc[r];
-            acc[r] = 0.f;
-        }
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                red[((mc * NWAVES + wave) * 64 + lane) * 4 + r] = acc[mc][r];
+                acc[mc][r] = 0.f;
+            }
         __syncthreads();
-        // 16 x 16 outputs: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
-        if (tid < 256)
+        // MC x (16 x 16) outputs: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+        if (tid < 256 * MC)
         {
-            const int om = tid >> 4, on = tid & 15;
-            const int src_lane = (om >> 2) * 16 + on, reg = om & 3;
+            const int mc = tid >> 8, om16 = (tid >> 4) & 15, on = tid & 15;
+            const int om = 16 * mc + om16;
+            const int src_lane = (om16 >> 2) * 16 + on, reg = om16 & 3;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w)
-                v += red[(w * 64 + src_lane) * 4 + reg];
+                v += red[((mc * NWAVES + w) * 64 + src_lane) * 4 + reg];
             if (om < rows)
             {
                 const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
@@ -276,7 +305,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     while (c_nb < nblocks)
     {
         load_next(cb);
-        gemv_compute_chunk<T, WBITS, CH, NSZ>(ca, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
+        gemv_compute_chunk<T, WBITS, CH, NSZ, MC>(ca, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
         if (++c_ck == cpw)
         {
             flush(c_nb);
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         if (c_nb >= nblocks)
             break;
         load_next(ca);
-        gemv_compute_chunk<T, WBITS, CH, NSZ>(cb, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
+        gemv_compute_chunk<T, WBITS, CH, NSZ, MC>(cb, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
         if (++c_ck == cpw)
         {
             flush(c_nb);
@@ -422,9 +451,19 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
 // Launch geometry of the decode kernel (see woq_gemv_kernel).
 struct GemvPlan
 {
-    int ksplit, nwaves, ch, ngroups;
+    int ksplit, nwaves, ch, ngroups, mc;
     size_t lds_bytes;
 };
+
+// Two 16-row chunks per block at most: the block's activation slab [rows][k segment] must fit LDS beside the reduce
+// buffer, and at 64 rows the k segments become so short (K/16) that most of a block's 16 waves idle (measured
+// 37 us vs 23 us for the prefill GEMM at 64 x 3584 x 8192; 32 rows: 17 us vs 19 us).  Larger m: prefill GEMM.
+constexpr int GEMV_MAX_M = 32;
+
+int gemv_mc(int m)
+{
+    return m > 32 ? 4 : (m > 16 ? 2 : 1);
+}
 
 constexpr int GEMV_CUS = 256;
 constexpr size_t GEMV_LDS_MAX = 160 * 1024 - 512;
@@ -433,15 +472,17 @@ size_t gemv_lds_bytes(int m, int k, int ktile, int ktiles, int ksplit, int nwave
 {
     const int seg = (ktiles + std::max(1, ksplit) - 1) / std::max(1, ksplit);
     const int krange = seg * ktile + (k - ktiles * ktile); // + the int4 half tile
-    return (size_t) nwaves * 64 * 4 * sizeof(float) + (size_t) std::min(16, m) * (krange * 2 + 32);
+    const int mc = gemv_mc(m);
+    return (size_t) mc * nwaves * 64 * 4 * sizeof(float) + (size_t) std::min(16 * mc, m) * (krange * 2 + 32);
 }
 
 GemvPlan plan_gemv(int m, int n, int k, int wbits)
 {
     const int ktile = wbits == 4 ? 128 : 64;
     const int ktiles = k / ktile;
-    const int nblocks = n / 16, mchunks = std::max(1, (m + 15) / 16);
     GemvPlan p{};
+    p.mc = gemv_mc(m);
+    const int nblocks = n / 16, mchunks = std::max(1, (m + 16 * p.mc - 1) / (16 * p.mc));
     p.nwaves = 16; // one 16-wave block per CU: all of a CU's waves finish an n-block together
     // k segments: (a) the activation slab of a segment must fit LDS, (b) when the n-blocks alone leave
     // most CUs idle, split K across blocks (fp32 slabs + a reduce launch, so only if really idle)
@@ -468,13 +509,13 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     return p;
 }
 
-template <typename T, int WBITS, bool ZERO, int NWAVES, int CH>
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int MC>
 void launch_gemv_variant(const WoqArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     // two (scale, zero) pairs per tile only when a 128-row int4 tile spans two groups of 64
     const bool split = WBITS == 4 && a.group == 64;
-    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1)>
-                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1>;
+    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1), MC>
+                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1, MC>;
     if (lds_bytes > 64 * 1024)
     {
         MQ_HIP(hipFuncSetAttribute(
@@ -498,11 +539,15 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
         const int tpw = (a.ktiles + p.nwaves - 1) / p.nwaves;
         q.ch = tpw >= 4 ? 4 : 2;
     }
-    dim3 grid(q.ngroups, (a.m + 15) / 16, q.ksplit);
-    if (q.ch == 4)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 4>(a, grid, q.lds_bytes, stream);
+    dim3 grid(q.ngroups, (a.m + 16 * q.mc - 1) / (16 * q.mc), q.ksplit);
+    if (q.mc == 4)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 4>(a, grid, q.lds_bytes, stream);
+    else if (q.mc == 2)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2>(a, grid, q.lds_bytes, stream);
+    else if (q.ch == 4)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 4, 1>(a, grid, q.lds_bytes, stream);
     else
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 1>(a, grid, q.lds_bytes, stream);
     if (a.ksplit > 1)
     {
         const size_t total = (size_t) a.m * a.n;
@@ -546,8 +591,8 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
     size_t best = 0;
     for (int mm = 1; mm <= m; mm = mm < 16 ? mm + 1 : mm + 16)
     {
-        const int s = woq_prefill_supported(mm, n, k) ? woq_prefill_ksplit(mm, n, k, weight_type)
-                                                        : woq_choose_ksplit(mm, n, k, weight_type);
+        const int s = (mm > GEMV_MAX_M && woq_prefill_supported(mm, n, k)) ? woq_prefill_ksplit(mm, n, k, weight_type)
+                                                                             : woq_choose_ksplit(mm, n, k, weight_type);
         if (s > 1)
             best = std::max(best, (size_t) s * mm * n * sizeof(float));
     }
@@ -573,10 +618,11 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
     if (p.m == 0)
         return;
     MQ_CHECK(p.act_scale == nullptr, "pre-quant scale must be applied with mi355q_apply_per_channel_scale first");
-    if (woq_prefill_supported(p.m, p.n, p.k) && !std::getenv("MI355Q_NO_PREFILL"))
+    static const int gemv_max_m = std::getenv("MI355Q_GEMV_MAX_M") ? atoi(std::getenv("MI355Q_GEMV_MAX_M")) : GEMV_MAX_M;
+    if (p.m > gemv_max_m && woq_prefill_supported(p.m, p.n, p.k) && !std::getenv("MI355Q_NO_PREFILL"))
     {
-        // m > 16: dequantise-in-registers MFMA GEMM (woq_prefill.hip); the decode kernel below would
-        // stream the weights once per 16 rows
+        // m > 64: dequantise-in-registers MFMA GEMM (woq_prefill.hip); the decode kernel below would
+        // stream the weights once per 64 rows
         const int ks = woq_prefill_ksplit(p.m, p.n, p.k, p.weight_type);
         const size_t need = (size_t) ks * p.m * p.n * sizeof(float);
         float* slabs = (ks > 1 && workspace && workspace_bytes >= need) ? reinterpret_cast<float*>(workspace) : nullptr;
