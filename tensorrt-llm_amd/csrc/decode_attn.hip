@@ -15,6 +15,7 @@
 //     keeps partials in fp32).
 //   * the new token's bias + RoPE + cache append (quantised for int8/fp8 caches) is fused in.
 #include "decode_common.h"
+#include <cstdlib>
 
 namespace mi355q
 {
@@ -386,6 +387,9 @@ int choose_splits(const mi355q_decode_attention_params& q, int tile)
 {
     if (q.multi_block_mode > 0)
         return std::min(q.multi_block_mode, 64); // the merge kernel handles up to 64 partials
+    static const int env_splits = getenv("MI355Q_ATTN_SPLITS") ? atoi(getenv("MI355Q_ATTN_SPLITS")) : 0; // lab
+    if (env_splits > 0)
+        return std::min(env_splits, std::max(1, (q.max_seq_len + tile - 1) / tile));
     const int wgs = q.batch * q.num_kv_heads;
     const int max_tiles = (q.max_seq_len + tile - 1) / tile;
     // aim for >= 4 workgroups per CU, never less than NW tiles per workgroup
