@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     const int bh = blockIdx.x / p.splits;
     const int hk = bh % p.num_kv_heads;
     const int b = bh / p.num_kv_heads;
-    const int Hq = p.num_heads, Hkv = p.num_kv_heads;
+    const int Hq = p.num_heads;
     const int tl = p.seq_lens[b] - 1; // cached tokens; the current token sits at position tl
     const int tpb = 1 << p.tpb_log2;
     const bool last_split = split == p.splits - 1;

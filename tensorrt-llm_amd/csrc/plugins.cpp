@@ -151,7 +151,7 @@ int rows_of(const mi355q_dims& d)
 // plugins/weightOnlyGroupwiseQuantMatmulPlugin/weightOnlyGroupwiseQuantMatmulPlugin.{h,cpp}
 constexpr int BIAS = 1, ZERO = 2, PRE_QUANT_SCALE = 4, FP8_ALPHA = 8; // :28-34
 constexpr int FP16_INT4_RATIO = 4;                                    // weightOnlyQuantMatmulPlugin.h:48
-constexpr int FP16_INT8_RATIO = 2;
+[[maybe_unused]] constexpr int FP16_INT8_RATIO = 2;
 
 struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
 {

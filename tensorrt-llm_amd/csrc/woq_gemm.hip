@@ -6,18 +6,17 @@
 //   * weights live in the GFX950 layout (preprocess.cpp): 1 KiB tiles of 16 columns x 128 (int4) or
 //     64 (int8) rows; one 16-byte load per lane is already the B fragment of 4 (2) consecutive
 //     v_mfma_f32_16x16x32 k-steps -- no LDS, no shuffles;
-//   * dequantisation in registers with the reference's single-rounding semantic
-//     w = round16(fma(q, scale, zero)) (kernel.h:364-365, mma_tensorop_dequantizer.h:244-252):
-//     v_cvt_f32_i32 (SDWA sign-extending byte select) + v_pk_fma_f32 + v_cvt_pk_{bf16,f16}_f32;
-//     the same device function backs mi355q_weight_only_dequantize, i.e. the bit-exact gate checks
-//     exactly the values the MFMA consumes;
-//   * decode (m <= 16 per block row): one workgroup = one 16-column n-block, 4 waves split K in
-//     chunks of 4 tiles; every wave issues a whole chunk (4 KiB of weights + activations + scales)
-//     as one burst of branch-free loads and keeps the next chunk in flight while it dequantises;
-//     fp32 MFMA accumulators are reduced through LDS.  The launch is HBM/VALU co-limited: the
-//     dequant costs ~2.8 VALU instructions per weight, so all 256 CUs must take part (N/16 blocks);
-//   * optional split-K across workgroups (fp32 slabs in the workspace + a tiny reduce kernel) when
-//     N/16 workgroups cannot fill the chip.
+//   * decode (m <= 32): the persistent kernel below.  One 16-wave workgroup per CU stages its activation rows in
+//     LDS once and walks its n-blocks; wave w owns a contiguous k-tile range and keeps two chunks of 2-4 KiB of
+//     weights in flight (ping-pong register images, nontemporal buffer loads with SGPR tile offsets).  int4 runs in
+//     the INTEGER domain: P = sum a*u and S1 = sum a on the MFMA (u = q + 8 unpacked exactly through the fp8
+//     converter), scale / zero applied to the group's partial sums -- about 8 VALU operations per scale group
+//     instead of ~2.8 per weight; int8 dequantises with the exact fma.  fp32 accumulators are reduced through LDS per
+//     n-block (two barriers) while the next n-block's weights are already in flight;
+//   * the bit-exact dequantisation w = round16(fma(q, scale, zero)) (kernel.h:364-365,
+//     mma_tensorop_dequantizer.h:244-252) backs mi355q_weight_only_dequantize and the prefill GEMM (woq_prefill.hip);
+//   * optional split-K across workgroups (fp32 slabs in the workspace + a small reduce kernel) when the activation
+//     slab of a workgroup would not fit LDS or N/16 workgroups cannot fill the chip.
 #include "woq_common.h"
 #include <cstdlib>
 
