@@ -7,18 +7,20 @@
 //     64 (int8) rows; one 16-byte load per lane is already the B fragment of 4 (2) consecutive
 //     v_mfma_f32_16x16x32 k-steps -- no LDS, no shuffles;
 //   * decode (m <= 32): the persistent kernel below.  One 16-wave workgroup per CU stages its activation rows in
-//     LDS once and walks its n-blocks; wave w owns a contiguous k-tile range and keeps two chunks of 2-4 KiB of
-//     weights in flight (ping-pong register images, nontemporal buffer loads with SGPR tile offsets).  int4 runs in
-//     the INTEGER domain: P = sum a*u and S1 = sum a on the MFMA (u = q + 8 unpacked exactly through the fp8
-//     converter), scale / zero applied to the group's partial sums -- about 8 VALU operations per scale group
-//     instead of ~2.8 per weight; int8 dequantises with the exact fma.  fp32 accumulators are reduced through LDS per
-//     n-block (two barriers) while the next n-block's weights are already in flight;
+//     LDS once and walks its n-blocks; wave w owns a contiguous k-tile range and keeps two chunks of 2 KiB of
+//     weights in flight while it computes a third (ring of register images, nontemporal buffer loads with SGPR tile
+//     offsets, issued unconditionally so the compiler's static vmcnt bookkeeping keeps them in flight).  int4 runs in
+//     the INTEGER domain: P = sum a*u on the MFMA (u = q + 8 unpacked exactly through the fp8 converter), S1 = sum a
+//     from a per-block LDS table, scale / zero applied to the group's partial sums -- about 8 VALU operations per
+//     scale group instead of ~2.8 per weight; int8 dequantises with the exact fma.  fp32 accumulators are reduced
+//     through LDS per n-block (one barrier) while the next n-blocks' weights are already in flight;
 //   * the bit-exact dequantisation w = round16(fma(q, scale, zero)) (kernel.h:364-365,
 //     mma_tensorop_dequantizer.h:244-252) backs mi355q_weight_only_dequantize and the prefill GEMM (woq_prefill.hip);
 //   * optional split-K across workgroups (fp32 slabs in the workspace + a small reduce kernel) when the activation
 //     slab of a workgroup would not fit LDS or N/16 workgroups cannot fill the chip.
 #include "woq_common.h"
 #include <cstdlib>
+#include <utility>
 
 namespace mi355q
 {
@@ -73,55 +75,66 @@ __device__ __forceinline__ f32x4_t gemv_step(const uint4& w, const uint4& av, fl
     return mfma16<T>(av, dequant_step<T, WBITS, ST>(w, s, z), acc);
 }
 
+// floats of the S1 table of a block: one per (64-row unit of its k range, row of its 16 * mc rows), rounded so the
+// activation slab behind it stays 16-byte aligned; sized for the finest unit (group size 64) whatever the group is
+// cross-wave reduce buffers: 2 x 16 KiB when a block handles 16 rows, 1 x 32 KiB when it handles 32
+__host__ __device__ constexpr int gemv_red_slots(int mc)
+{
+    return mc == 1 ? 2 : 1;
+}
+
+__host__ __device__ constexpr int gemv_s1_floats(int krange, int mc)
+{
+    return ((krange + 63) / 64) * 16 * mc;
+}
+
 // One int4 k-tile (STEPS k-steps of 32 rows) in the integer domain.  Per scale group g of the tile:
 //     P  = sum_k a[m,k] * u[k,n]      (MFMA, u = q + 8 exact in 16 bits, fp32 accumulate)
-//     S1 = sum_k a[m,k]               (MFMA against ones)
+//     S1 = sum_k a[m,k]               (depends on the activations only: summed once per block while they are staged,
+//                                      `s1frag(mc, h)` reads the lane's 4 rows of it from LDS)
 //     acc += scale * P + (zero - 8 * scale) * S1   ==   sum_k a * (q * scale + zero)
 // i.e. the scale / zero are applied to the group's partial sums (8-9 VALU ops per group) instead of
 // to every weight.  Unlike kernel.h:364-365 / mma_tensorop_dequantizer.h the dequantised weight is
 // not rounded to 16 bits before the multiply, so results differ from the exact-dequant path by
 // about half an output ulp (closer to the real-number result); mi355q_weight_only_dequantize and
 // the prefill GEMM keep the bit-exact rounding.
-template <typename T, int NSZ, int STEPS, int MC, typename AF>
-__device__ __forceinline__ void gemv_tile_int4(const uint4& w, f32x4_t (&acc)[MC], const float* s, const float* z, AF afrag)
+template <typename T, int NSZ, int STEPS, int MC, typename AF, typename SF>
+__device__ __forceinline__ void gemv_tile_int4(
+    const uint4& w, f32x4_t (&acc)[MC], const float* s, const float* z, AF afrag, SF s1frag)
 {
     const uint32_t* wd = reinterpret_cast<const uint32_t*>(&w);
     constexpr int PER = STEPS / NSZ; // k-steps per scale group
 #pragma unroll
     for (int h = 0; h < NSZ; ++h)
     {
-        f32x4_t P[MC], S1[MC];
+        f32x4_t P[MC];
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
-        {
             P[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            S1[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int st = h * PER; st < (h + 1) * PER; ++st)
         {
             const auto u = unpack8_u4<T>(wd[st]); // unpacked once, used by every 16-row chunk of m
 #pragma unroll
             for (int mc = 0; mc < MC; ++mc)
-            {
-                const uint4 av = afrag(mc, st);
-                P[mc] = mfma16<T>(av, u, P[mc]);
-                S1[mc] = mfma16<T>(av, ones8<T>(), S1[mc]);
-            }
+                P[mc] = mfma16<T>(afrag(mc, st), u, P[mc]);
         }
         const float zc = fmaf(-8.f, s[h], z[h]);
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
+        {
+            const f32x4_t S1 = s1frag(mc, h);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[mc][r] = fmaf(zc, S1[mc][r], fmaf(s[h], P[mc][r], acc[mc][r]));
+                acc[mc][r] = fmaf(zc, S1[r], fmaf(s[h], P[mc][r], acc[mc][r]));
+        }
     }
 }
 
 // `afrag(mc, kt, st)` returns the activation fragment of k-step st of tile kt for m-chunk mc (LDS).
-template <typename T, int WBITS, int CH, int NSZ, int MC, typename AF>
+template <typename T, int WBITS, int CH, int NSZ, int MC, typename AF, typename SF>
 __device__ __forceinline__ void gemv_compute_chunk(
-    const GemvChunk<CH, NSZ>& c, f32x4_t (&acc)[MC], int kt0, int kt_end, int kt_last, AF afrag)
+    const GemvChunk<CH, NSZ>& c, f32x4_t (&acc)[MC], int kt0, int kt_end, int kt_last, AF afrag, SF s1frag)
 {
 #pragma unroll
     for (int i = 0; i < CH; ++i)
@@ -139,7 +152,9 @@ __device__ __forceinline__ void gemv_compute_chunk(
             z[h] = T16<T>::to_float(c.z[i][h]);
         }
         if constexpr (WBITS == 4)
-            gemv_tile_int4<T, NSZ, 4, MC>(c.w[i], acc, s, z, [&](int mc, int st) { return afrag(mc, kt, st); });
+            gemv_tile_int4<T, NSZ, 4, MC>(
+                c.w[i], acc, s, z, [&](int mc, int st) { return afrag(mc, kt, st); },
+                [&](int mc, int h) { return s1frag(mc, kt, h); });
         else
         {
             const auto w0 = dequant_step<T, 8, 0>(c.w[i], s[0], z[0]);
@@ -154,6 +169,13 @@ __device__ __forceinline__ void gemv_compute_chunk(
     }
 }
 
+// step(0) || step(1) || ... : one trip round the register ring, stops at the first position that reports "done"
+template <typename F, int... B>
+__device__ __forceinline__ bool gemv_ring_round(F& step, std::integer_sequence<int, B...>)
+{
+    return (step(std::integral_constant<int, B>{}) || ...);
+}
+
 // Persistent decode kernel.  grid: x = n-group, y = 16-row chunk of m, z = k segment; block =
 // NWAVES waves.  A block stages its activation rows [rows][k segment] into LDS once (row stride
 // kseg*2+32 bytes: conflict-free ds_read_b128 fragments) and then walks the n-blocks x, x+gridDim.x,
@@ -161,15 +183,20 @@ __device__ __forceinline__ void gemv_compute_chunk(
 // runs ONE ping-pong load pipeline over the whole (n-block, chunk) sequence, so the next n-block's
 // weights are already in flight while the current one is reduced (LDS, one 16x16 tile per n-block)
 // and stored -- the HBM queue never drains between n-blocks.
-// MC = 16-row chunks of m handled by one block (1, 2, 4): for 16 < m <= 64 the weights are still streamed ONCE and
+// MC = 16-row chunks of m handled by one block (1, 2): for 16 < m <= 32 the weights are still streamed ONCE and
 // every unpacked fragment feeds MC MFMAs (the prefill GEMM's 2-barrier tile loop is latency-bound at these sizes).
-template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ, int MC>
+// NBUF = register images in the ring (NBUF - 1 chunks of CH tiles in flight during a chunk's compute).
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ, int MC, int NBUF>
 __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
     constexpr int KTILE = Geo<WBITS>::KTILE;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // red[MC][NWAVES][64][4] floats, then A rows
+    // LDS: red[RB][MC][NWAVES][64][4] floats | s1[units][16 * MC] floats | activation rows
+    constexpr int RB = gemv_red_slots(MC); // reduce buffers: two (one barrier per n-block) when they are small
+    constexpr int UNIT = KTILE / NSZ;      // k rows that share one (scale, zero): the granule of S1
+    constexpr int RED_FLOATS = MC * NWAVES * 64 * 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = reinterpret_cast<float*>(smem);
-    uint8_t* a_lds = smem + MC * NWAVES * 64 * 4 * sizeof(float);
+    float* s1_lds = red + RB * RED_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -179,6 +206,15 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     const int rows = min(16 * MC, a.m - m0);
     const int nblocks = a.n >> 4;
     const int nb_stride = gridDim.x;
+    // Workgroups go to the 8 XCDs round-robin, so blocks with equal blockIdx.x % 8 share an L2.  Give each XCD a
+    // contiguous range of n-blocks per round: a 128-byte line of scales / zeros covers 4 n-blocks, and with
+    // neighbouring n-blocks on different XCDs every line was fetched from HBM by 4 L2s (PMC: 147 MB read per launch
+    // at 28672 x 8192 against 125 MB algorithmic).
+    int nb_first;
+    {
+        const int q = nb_stride / 8, r = nb_stride % 8, x = blockIdx.x % 8;
+        nb_first = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8;
+    }
 
     // k segment of this block, and this wave's contiguous tile range in it
     const int seg = (a.ktiles + a.ksplit - 1) / a.ksplit; // 0 when k == 64 on int4: half tile only
@@ -201,40 +237,83 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     src.w_voff = lane * 16;
     src.group_shift = a.group_shift;
     src.row_bytes = a.n * 2;
-    auto issue = [&](GemvChunk<CH, NSZ>& c, int nb, int ck)
+    const __amdgpu_buffer_rsrc_t s_rsrc = src.s, z_rsrc = src.z;
+    const __amdgpu_buffer_rsrc_t s_dead = make_rsrc(a.scales, 0), z_dead = make_rsrc(a.scales, 0);
+    // `live == false` (past the block's last n-block): the same loads against zero-sized descriptors -- they return 0
+    // without touching memory.  The loads must not sit under a branch: the compiler counts vmcnt statically, and a
+    // path that issues nothing forces `s_waitcnt vmcnt(0)` on the chunk computed next, i.e. a wait for the chunk
+    // that was requested a moment ago (no prefetch at all).
+    auto issue = [&](GemvChunk<CH, NSZ>& c, int nb, int ck, bool live)
     {
-        src.w = make_rsrc(a.qweight + (size_t) nb * run_bytes, run_bytes);
+        src.w = make_rsrc(a.qweight + (size_t) nb * run_bytes, live ? run_bytes : 0);
+        src.s = live ? s_rsrc : s_dead;
+        src.z = live ? z_rsrc : z_dead;
         src.sz_voff = (nb * 16 + (lane & 15)) * 2;
         gemv_load_chunk<WBITS, ZERO, CH, NSZ>(c, src, kt_begin + ck * CH, kt_hi);
     };
 
     // rows >= m are clamped to the last valid row: their MFMA output rows are computed, never stored
     const int lds_stride = (k_hi - k_lo) * 2 + 32;
+    const int units = (k_hi - k_lo + UNIT - 1) / UNIT;
+    uint8_t* a_lds = reinterpret_cast<uint8_t*>(s1_lds + gemv_s1_floats(k_hi - k_lo, MC));
 
-    GemvChunk<CH, NSZ> ca, cb;
-    int l_nb = blockIdx.x, l_ck = 0; // next chunk to load
+    GemvChunk<CH, NSZ> ring[NBUF];
+    int l_nb = nb_first, l_ck = 0; // next chunk to load
     auto load_next = [&](GemvChunk<CH, NSZ>& c)
     {
-        if (l_nb < nblocks)
+        const bool live = l_nb < nblocks;
+        issue(c, live ? l_nb : 0, l_ck, live);
+        if (++l_ck == cpw)
         {
-            issue(c, l_nb, l_ck);
-            if (++l_ck == cpw)
-            {
-                l_ck = 0;
-                l_nb += nb_stride;
-            }
+            l_ck = 0;
+            l_nb += nb_stride;
         }
     };
-    load_next(ca); // weights first: their HBM latency overlaps the activation staging below
+    // weights first: their HBM latency overlaps the activation staging below
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        load_next(ring[b]);
 
     {
-        const int vec_per_row = (k_hi - k_lo) / 8; // 16-byte vectors
-        for (int i = tid; i < rows * vec_per_row; i += NWAVES * 64)
+        // stage the rows; int4: the same pass sums every UNIT of k per row (S1 of gemv_tile_int4) -- a thread adds its
+        // 8 values, the UNIT / 8 neighbouring lanes that hold one unit combine through shuffles
+        constexpr int VPU = UNIT / 8;                        // 16-byte vectors per unit (16 or 8)
+        const int vec_per_row = (k_hi - k_lo) / 8;           // multiple of 8 (k % 64 == 0)
+        const int vpr_pad = (vec_per_row + VPU - 1) / VPU * VPU;
+        const int total = rows * vpr_pad;
+        for (int base = tid - lane; base < total; base += NWAVES * 64)
         {
-            const int r = i / vec_per_row, v = i - r * vec_per_row;
-            *reinterpret_cast<uint4*>(a_lds + r * lds_stride + v * 16)
-                = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
+            const int i = base + lane;
+            const int r = i / vpr_pad, v = i - r * vpr_pad;
+            const bool valid = i < total && v < vec_per_row;
+            float part = 0.f;
+            if (valid)
+            {
+                const uint4 x = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
+                *reinterpret_cast<uint4*>(a_lds + r * lds_stride + v * 16) = x;
+                if constexpr (WBITS == 4)
+                {
+                    const uint32_t* xd = reinterpret_cast<const uint32_t*>(&x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        part += T16<T>::to_float((uint16_t) (xd[j] & 0xffffu)) + T16<T>::to_float((uint16_t) (xd[j] >> 16));
+                }
+            }
+            if constexpr (WBITS == 4)
+            {
+                part += __shfl_xor(part, 1);
+                part += __shfl_xor(part, 2);
+                part += __shfl_xor(part, 4);
+                if constexpr (VPU == 16)
+                    part += __shfl_xor(part, 8);
+                if (valid && (v & (VPU - 1)) == 0)
+                    s1_lds[(v / VPU) * (16 * MC) + r] = part;
+            }
         }
+        if constexpr (WBITS == 4) // rows past m: never stored, keep them finite
+            for (int i = tid; i < units * 16 * MC; i += NWAVES * 64)
+                if ((i & (16 * MC - 1)) >= rows)
+                    s1_lds[i] = 0.f;
     }
     __syncthreads();
     const uint8_t* a_lane[MC];
@@ -243,6 +322,10 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         a_lane[mc] = a_lds + min(16 * mc + (lane & 15), rows - 1) * lds_stride + (kh - k_lo) * 2;
     auto afrag = [&](int mc, int kt, int st) -> uint4
     { return *reinterpret_cast<const uint4*>(a_lane[mc] + (kt * KTILE + st * 32) * 2); };
+    // the lane's 4 output rows (C/D map: row = 4 * (lane >> 4) + reg) of S1 for scale unit h of tile kt
+    const float* s1_lane = s1_lds + (lane >> 4) * 4 - seg_begin * NSZ * 16 * MC;
+    auto s1frag = [&](int mc, int kt, int h) -> f32x4_t
+    { return *reinterpret_cast<const f32x4_t*>(s1_lane + ((kt * NSZ + h) * MC + mc) * 16); };
 
     f32x4_t acc[MC];
 #pragma unroll
@@ -250,6 +333,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         acc[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // end of an n-block: (half tile,) cross-wave reduce, bias, store
+    int it = 0; // n-blocks this block has finished (the same sequence in every wave)
     auto flush = [&](int nb)
     {
         if (half_tile && wave == 0)
@@ -263,17 +347,28 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
             const float z = ZERO ? T16<T>::to_float(a.zeros[si]) : 0.f;
             const uint4 w = make_uint4(hw.x, hw.y, 0, 0);
             if constexpr (WBITS == 4)
-                gemv_tile_int4<T, 1, 2, MC>(w, acc, &s, &z, [&](int mc, int st) { return afrag(mc, a.ktiles, st); });
+                gemv_tile_int4<T, 1, 2, MC>(
+                    w, acc, &s, &z, [&](int mc, int st) { return afrag(mc, a.ktiles, st); },
+                    [&](int mc, int) { return s1frag(mc, a.ktiles, 0); });
         }
-        __syncthreads(); // the previous n-block's readers are done with `red`
+        // RB == 2: this n-block's buffer was last read two n-blocks ago, and every reader has passed the barrier of the
+        // n-block in between -- one barrier per n-block.  (Tried: no barrier at all -- every wave counts itself into
+        // the slot with an LDS atomic and the last arriver sums the 16 partials.  Slower, 27.5 us against 24.9 at
+        // 28672 x 8192: the reduction then always lands on the wave that is already last.)
+        float* red_nb = red;
+        if constexpr (RB == 2)
+        {
+            red_nb = red + (it & 1) * RED_FLOATS;
+            ++it;
+        }
+        else
+            __syncthreads(); // the previous n-block's readers are done with `red`
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                red[((mc * NWAVES + wave) * 64 + lane) * 4 + r] = acc[mc][r];
-                acc[mc][r] = 0.f;
-            }
+        {
+            *reinterpret_cast<f32x4_t*>(red_nb + ((mc * NWAVES + wave) * 64 + lane) * 4) = acc[mc];
+            acc[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
         // MC x (16 x 16) outputs: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
         if (tid < 256 * MC)
@@ -284,7 +379,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w)
-                v += red[((mc * NWAVES + w) * 64 + src_lane) * 4 + reg];
+                v += red_nb[((mc * NWAVES + w) * 64 + src_lane) * 4 + reg];
             if (om < rows)
             {
                 const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
@@ -300,27 +395,27 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         }
     };
 
-    int c_nb = blockIdx.x, c_ck = 0; // chunk being computed (held by `ca` at the loop head)
-    while (c_nb < nblocks)
+    // ring of NBUF register images: NBUF - 1 chunks are in flight while one is computed (a wave that holds a single
+    // chunk in flight during its compute phase runs at one chunk per max(compute, HBM latency under load))
+    int c_nb = nb_first, c_ck = 0; // chunk being computed (held by ring[0] at the loop head)
+    // one ring position; the positions are expanded statically (fold below) so every image stays in registers
+    auto step = [&](auto pos) -> bool
     {
-        load_next(cb);
-        gemv_compute_chunk<T, WBITS, CH, NSZ, MC>(ca, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
-        if (++c_ck == cpw)
-        {
-            flush(c_nb);
-            c_ck = 0;
-            c_nb += nb_stride;
-        }
+        constexpr int b = decltype(pos)::value;
         if (c_nb >= nblocks)
-            break;
-        load_next(ca);
-        gemv_compute_chunk<T, WBITS, CH, NSZ, MC>(cb, acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag);
+            return true;
+        load_next(ring[(b + NBUF - 1) % NBUF]);
+        gemv_compute_chunk<T, WBITS, CH, NSZ, MC>(ring[b], acc, kt_begin + c_ck * CH, kt_end, kt_hi, afrag, s1frag);
         if (++c_ck == cpw)
         {
             flush(c_nb);
             c_ck = 0;
             c_nb += nb_stride;
         }
+        return false;
+    };
+    while (!gemv_ring_round(step, std::make_integer_sequence<int, NBUF>{}))
+    {
     }
 }
 
@@ -450,7 +545,7 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
 // Launch geometry of the decode kernel (see woq_gemv_kernel).
 struct GemvPlan
 {
-    int ksplit, nwaves, ch, ngroups, mc;
+    int ksplit, nwaves, ngroups, mc;
     size_t lds_bytes;
 };
 
@@ -461,7 +556,7 @@ constexpr int GEMV_MAX_M = 32;
 
 int gemv_mc(int m)
 {
-    return m > 32 ? 4 : (m > 16 ? 2 : 1);
+    return m > 16 ? 2 : 1;
 }
 
 constexpr int GEMV_CUS = 256;
@@ -472,7 +567,8 @@ size_t gemv_lds_bytes(int m, int k, int ktile, int ktiles, int ksplit, int nwave
     const int seg = (ktiles + std::max(1, ksplit) - 1) / std::max(1, ksplit);
     const int krange = seg * ktile + (k - ktiles * ktile); // + the int4 half tile
     const int mc = gemv_mc(m);
-    return (size_t) mc * nwaves * 64 * 4 * sizeof(float) + (size_t) std::min(16 * mc, m) * (krange * 2 + 32);
+    return (size_t) gemv_red_slots(mc) * mc * nwaves * 64 * 4 * sizeof(float) + (size_t) gemv_s1_floats(krange, mc) * sizeof(float)
+        + (size_t) std::min(16 * mc, m) * (krange * 2 + 32);
 }
 
 GemvPlan plan_gemv(int m, int n, int k, int wbits)
@@ -497,8 +593,6 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     }
     const int seg = std::max(1, (ktiles + ks - 1) / ks);
     p.ksplit = std::max(1, (ktiles + seg - 1) / seg); // no empty trailing segment
-    const int tpw = (seg + p.nwaves - 1) / p.nwaves;
-    p.ch = tpw >= 4 ? 4 : 2;
     // n-groups: one block per CU, n-blocks dealt round-robin, every block the same count (+-1)
     const int slots = std::max(1, GEMV_CUS / (mchunks * p.ksplit));
     const int iters = (nblocks + slots - 1) / slots;
@@ -508,13 +602,13 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     return p;
 }
 
-template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int MC>
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int MC, int NBUF>
 void launch_gemv_variant(const WoqArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     // two (scale, zero) pairs per tile only when a 128-row int4 tile spans two groups of 64
     const bool split = WBITS == 4 && a.group == 64;
-    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1), MC>
-                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1, MC>;
+    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1), MC, NBUF>
+                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1, MC, NBUF>;
     if (lds_bytes > 64 * 1024)
     {
         MQ_HIP(hipFuncSetAttribute(
@@ -535,18 +629,21 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
         q.lds_bytes = gemv_lds_bytes(a.m, a.k, Geo<WBITS>::KTILE, a.ktiles, 1, p.nwaves);
         MQ_CHECK(q.lds_bytes <= GEMV_LDS_MAX,
             "this m/k needs the split-K workspace (mi355q_weight_only_gemm_workspace_size)");
-        const int tpw = (a.ktiles + p.nwaves - 1) / p.nwaves;
-        q.ch = tpw >= 4 ? 4 : 2;
     }
     dim3 grid(q.ngroups, (a.m + 16 * q.mc - 1) / (16 * q.mc), q.ksplit);
-    if (q.mc == 4)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 4>(a, grid, q.lds_bytes, stream);
+    // ring geometry: 3 register images of 2 tiles (measured best of {2x4, 3x4, 4x2, 6x2, 3x2, 4x1, 6x1, 8x1} at
+    // 28672 x 8192 and no worse elsewhere); MI355Q_GEMV_RING = 10 * images + tiles selects the lab alternatives
+    static const int lab = getenv("MI355Q_GEMV_RING") ? atoi(getenv("MI355Q_GEMV_RING")) : 0;
+    if (q.mc == 2 && lab == 32)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 3>(a, grid, q.lds_bytes, stream);
     else if (q.mc == 2)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2>(a, grid, q.lds_bytes, stream);
-    else if (q.ch == 4)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 4, 1>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 2>(a, grid, q.lds_bytes, stream);
+    else if (lab == 24)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 4, 1, 2>(a, grid, q.lds_bytes, stream);
+    else if (lab == 41)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 1, 1, 4>(a, grid, q.lds_bytes, stream);
     else
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 1>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 1, 3>(a, grid, q.lds_bytes, stream);
     if (a.ksplit > 1)
     {
         const size_t total = (size_t) a.m * a.n;
@@ -588,7 +685,7 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
 {
     // worst case over all m' <= m of ksplit(m') * m' * n fp32 slabs
     size_t best = 0;
-    for (int mm = 1; mm <= m; mm = mm < 16 ? mm + 1 : mm + 16)
+    for (int mm = 1; mm <= m; mm = (mm < 64 || m - mm < 16) ? mm + 1 : mm + 16) // every m' up to 64, then 16s, then m
     {
         const int s = (mm > GEMV_MAX_M && woq_prefill_supported(mm, n, k)) ? woq_prefill_ksplit(mm, n, k, weight_type)
                                                                              : woq_choose_ksplit(mm, n, k, weight_type);

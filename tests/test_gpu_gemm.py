@@ -79,6 +79,13 @@ def test_groupwise_baseline_cfg1_shape(cuda, dtype_str, m):
     _groupwise_case(m, 4096, 4096, dtype_str, True, True, False, 128, cuda)
 
 
+@pytest.mark.parametrize("m", [17, 24, 31, 32])
+def test_groupwise_two_row_chunks_large_k(cuda, m):
+    # 16 < m <= 32 stays on the decode kernel (two 16-row chunks per block); at k = 8192 its activation slab needs
+    # split-K, so the workspace query must cover every m' <= m, not only multiples of 16 (m = 24 used to fail)
+    _groupwise_case(m, 2048, 8192, "bfloat16", False, True, True, 128, cuda)
+
+
 def test_groupwise_empty_batch(cuda):
     dt = torch.float16
     w = torch.zeros(64, 16, dtype=dt, device=cuda)

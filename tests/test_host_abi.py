@@ -271,6 +271,9 @@ def test_allreduce_strategy_selection_matches_reference():
 def test_workspace_size_queries_are_pure_host():
     n = L.lib().mi355q_weight_only_gemm_workspace_size(16, 4096, 4096, 2)
     assert n >= 16 * 4096 * 2
+    # the answer covers every m' <= m (an engine is built for a maximum m): monotonic in m, also between 16-steps
+    ws = [L.lib().mi355q_weight_only_gemm_workspace_size(m, 2048, 8192, 2) for m in range(1, 70)]
+    assert all(b >= a for a, b in zip(ws, ws[1:])) and ws[23] > ws[15]
     p = L.DecodeAttentionParams()
     p.batch, p.num_heads, p.num_kv_heads, p.head_size = 64, 8, 1, 128
     p.max_blocks_per_seq, p.tokens_per_block, p.max_seq_len = 32, 64, 2048
