@@ -10,6 +10,7 @@
 // output pass (16-byte loads, 8 elements per chunk), so HBM traffic is the algorithmic minimum: the row read once,
 // the int8 (or T) row written once.  Rows longer than 16384 or not a multiple of 8 take a re-reading scalar kernel.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mi355q
 {
@@ -87,12 +88,28 @@ struct NormIO<bf16_t> : NormIO16<bf16_t>
 {
 };
 
+__device__ __forceinline__ float quant_rni_sat_f(float x)
+{
+    // cvt.rni.sat.s8.f32 (common/cudaTypeUtils.cuh cuda_cast<int8_t, float>) in two operations: clamp to [-128, 127],
+    // then add 1.5 * 2^23 -- the sum's unit in the last place is 1, so the addition itself rounds to nearest-even, and
+    // the low byte of the result's bit pattern is the two's-complement int8 (clamping first or rounding first gives
+    // the same integer: the bounds are integers)
+    return __builtin_amdgcn_fmed3f(x, -128.f, 127.f) + 12582912.f;
+}
+
 __device__ __forceinline__ uint32_t quant_rni_sat(float x)
 {
-    // cvt.rni.sat.s8.f32 (common/cudaTypeUtils.cuh cuda_cast<int8_t, float>)
-    float r = rintf(x);
-    r = fminf(fmaxf(r, -128.f), 127.f);
-    return (uint32_t) (uint8_t) (int8_t) (int) r;
+    return __builtin_bit_cast(uint32_t, quant_rni_sat_f(x)) & 0xffu;
+}
+
+// four products -> four int8 in one dword (v_perm_b32 gathers the low bytes: 2.75 VALU operations per element)
+__device__ __forceinline__ uint32_t quant4_rni_sat(float a, float b, float c, float d)
+{
+    const uint32_t za = __builtin_bit_cast(uint32_t, quant_rni_sat_f(a)), zb = __builtin_bit_cast(uint32_t, quant_rni_sat_f(b));
+    const uint32_t zc = __builtin_bit_cast(uint32_t, quant_rni_sat_f(c)), zd = __builtin_bit_cast(uint32_t, quant_rni_sat_f(d));
+    uint32_t w = __builtin_amdgcn_perm(zb, za, 0x0c0c0400u); // byte 0 <- za.0, byte 1 <- zb.0
+    w = __builtin_amdgcn_perm(zc, w, 0x0c040100u);           // keep bytes 0, 1; byte 2 <- zc.0
+    return __builtin_amdgcn_perm(zd, w, 0x04020100u);        // keep bytes 0..2; byte 3 <- zd.0
 }
 
 struct NormArgs
@@ -108,8 +125,8 @@ struct NormArgs
     int tokens, hidden;
 };
 
-// block-wide sum / max over 256 threads; every thread gets the result
-template <bool MAX>
+// block-wide sum / max over NT threads (1, 2 or 4 waves); every thread gets the result.  One wave: shuffles only.
+template <bool MAX, int NT = 256>
 __device__ __forceinline__ float block_reduce(float v, float* sm)
 {
 #pragma unroll
@@ -118,74 +135,151 @@ __device__ __forceinline__ float block_reduce(float v, float* sm)
         const float o = __shfl_xor(v, off);
         v = MAX ? fmaxf(v, o) : v + o;
     }
-    const int wave = threadIdx.x >> 6;
-    __syncthreads(); // sm may still be read from the previous reduction
-    if ((threadIdx.x & 63) == 0)
-        sm[wave] = v;
-    __syncthreads();
-    return MAX ? fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if constexpr (NT == 64)
+        return v;
+    else
+    {
+        const int wave = threadIdx.x >> 6;
+        __syncthreads(); // sm may still be read from the previous reduction
+        if ((threadIdx.x & 63) == 0)
+            sm[wave] = v;
+        __syncthreads();
+        if constexpr (NT == 128)
+            return MAX ? fmaxf(sm[0], sm[1]) : sm[0] + sm[1];
+        else
+            return MAX ? fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int norm_u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int norm_u32x2_t;
+
+// buffer descriptor over `bytes` bytes at p (wave-uniform): loads past the end return 0, stores past the end are dropped
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t norm_rsrc(const void* p, uint32_t bytes)
+{
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*) (((uint64_t) hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
+// 8 consecutive elements at element offset i0 of the buffer (zeros past the end): the raw load, and its conversion
+template <typename T>
+struct NormRaw
+{
+    norm_u32x4_t v[sizeof(T) == 4 ? 2 : 1];
+};
+
+template <typename T>
+__device__ __forceinline__ NormRaw<T> norm_load8_raw(__amdgpu_buffer_rsrc_t rs, int i0)
+{
+    NormRaw<T> r;
+    if constexpr (sizeof(T) == 4)
+    {
+        r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 4, 0, 0);
+        r.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 4 + 16, 0, 0);
+    }
+    else
+        r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 2, 0, 0);
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void norm_cvt8(const NormRaw<T>& r, float (&x)[8])
+{
+    if constexpr (sizeof(T) == 4)
+    {
+        const uint32_t u[8] = {r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w, r.v[1].x, r.v[1].y, r.v[1].z, r.v[1].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            x[j] = __builtin_bit_cast(float, u[j]);
+    }
+    else
+    {
+        const uint32_t u[4] = {r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            x[2 * j] = T16<T>::lo(u[j]);
+            x[2 * j + 1] = T16<T>::hi(u[j]);
+        }
+    }
 }
 
 // MODE: 0 RMSNorm, 1 LayerNorm two-pass variance, 2 LayerNorm E[x^2] - E[x]^2 (use_diff_of_squares)
-template <typename T, int MODE, int VPT>
-__global__ __launch_bounds__(256) void norm_quant_kernel(NormArgs a)
+// No load or store sits under a branch (buffer descriptors bound the row instead): hipcc counts vmcnt statically, and
+// with each chunk's load and first use inside `if (live)` the chunks of a row were fetched one HBM round trip after
+// the other.
+template <typename T, int MODE, int VPT, int NT>
+__global__ __launch_bounds__(NT) void norm_quant_kernel(NormArgs a)
 {
     __shared__ float sm[4];
     const size_t row = blockIdx.x;
     const size_t base = row * a.hidden;
+    const uint32_t row_bytes = (uint32_t) a.hidden * sizeof(T);
+    const __amdgpu_buffer_rsrc_t in_rs = norm_rsrc(static_cast<const char*>(a.input) + base * sizeof(T), row_bytes);
+    const __amdgpu_buffer_rsrc_t g_rs = norm_rsrc(a.gamma, row_bytes);
+    const __amdgpu_buffer_rsrc_t b_rs = norm_rsrc(a.beta ? a.beta : a.gamma, a.beta ? row_bytes : 0);
     float x[VPT][8];
-    bool live[VPT];
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < VPT; ++c)
     {
-        const int i0 = (c * 256 + threadIdx.x) * 8;
-        live[c] = i0 < a.hidden;
-        if (live[c])
+        NormRaw<T> raw[VPT];
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+            raw[c] = norm_load8_raw<T>(in_rs, (c * NT + threadIdx.x) * 8);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
         {
-            NormIO<T>::load8(a.input, base + i0, x[c]);
+            norm_cvt8<T>(raw[c], x[c]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
             {
-                s1 += x[c][j];
+                s1 += x[c][j]; // elements past the row are 0
                 s2 += x[c][j] * x[c][j];
             }
         }
     }
     float mean = 0.f, rstd;
     if (MODE == 0)
-        rstd = rsqrtf(block_reduce<false>(s2, sm) / a.hidden + a.eps);
+        rstd = rsqrtf(block_reduce<false, NT>(s2, sm) / a.hidden + a.eps);
     else if (MODE == 2)
     {
-        mean = block_reduce<false>(s1, sm) / a.hidden;
-        rstd = rsqrtf(block_reduce<false>(s2, sm) / a.hidden - mean * mean + a.eps);
+        mean = block_reduce<false, NT>(s1, sm) / a.hidden;
+        rstd = rsqrtf(block_reduce<false, NT>(s2, sm) / a.hidden - mean * mean + a.eps);
     }
     else
     {
-        mean = block_reduce<false>(s1, sm) / a.hidden;
+        mean = block_reduce<false, NT>(s1, sm) / a.hidden;
         float v = 0.f;
 #pragma unroll
         for (int c = 0; c < VPT; ++c)
-            if (live[c])
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                {
-                    const float d = x[c][j] - mean;
-                    v += d * d;
-                }
-        rstd = rsqrtf(block_reduce<false>(v, sm) / a.hidden + a.eps);
-    }
-    // normalise, round to T
-    float amax = NormIO<T>::round(1e-6f);
-#pragma unroll
-    for (int c = 0; c < VPT; ++c)
-        if (live[c])
         {
-            const int i0 = (c * 256 + threadIdx.x) * 8;
+            const bool live = (c * NT + (int) threadIdx.x) * 8 < a.hidden;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const float d = x[c][j] - mean;
+                v += live ? d * d : 0.f;
+            }
+        }
+        rstd = rsqrtf(block_reduce<false, NT>(v, sm) / a.hidden + a.eps);
+    }
+    // normalise, round to T (gamma / beta past the row read as 0, so the dead elements become 0 and leave amax alone)
+    float amax = NormIO<T>::round(1e-6f);
+    {
+        NormRaw<T> graw[VPT], braw[VPT];
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+            graw[c] = norm_load8_raw<T>(g_rs, (c * NT + threadIdx.x) * 8);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c) // without beta: a zero-sized descriptor, the loads return 0 and cost no memory access
+            braw[c] = norm_load8_raw<T>(b_rs, (c * NT + threadIdx.x) * 8);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+        {
             float g[8], b[8];
-            NormIO<T>::load8(a.gamma, i0, g);
-            if (a.beta)
-                NormIO<T>::load8(a.beta, i0, b);
+            norm_cvt8<T>(graw[c], g);
+            norm_cvt8<T>(braw[c], b);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
             {
@@ -196,32 +290,36 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormArgs a)
                 amax = fmaxf(amax, fabsf(x[c][j]));
             }
         }
+    }
     float scale = 0.f;
     if (a.scale_per_token)
     {
-        amax = block_reduce<true>(amax, sm);
+        amax = block_reduce<true, NT>(amax, sm);
         scale = 127.f / amax;
         if (threadIdx.x == 0)
             a.scale_per_token[row] = amax / 127.f;
     }
     else if (a.scale_per_tensor)
         scale = a.scale_per_tensor[0];
+    if (a.scale_per_token || a.scale_per_tensor)
+    {
+        const __amdgpu_buffer_rsrc_t q_rs = norm_rsrc(a.out_quant + base, (uint32_t) a.hidden);
 #pragma unroll
-    for (int c = 0; c < VPT; ++c)
-        if (live[c])
+        for (int c = 0; c < VPT; ++c)
         {
-            const int i0 = (c * 256 + threadIdx.x) * 8;
-            if (a.scale_per_token || a.scale_per_tensor)
-            {
-                uint32_t w[2] = {0, 0};
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    w[j >> 2] |= quant_rni_sat(x[c][j] * scale) << (8 * (j & 3));
-                *reinterpret_cast<uint2*>(a.out_quant + base + i0) = make_uint2(w[0], w[1]);
-            }
-            else
-                NormIO<T>::store8(a.out, base + i0, x[c]);
+            norm_u32x2_t w;
+            w.x = quant4_rni_sat(x[c][0] * scale, x[c][1] * scale, x[c][2] * scale, x[c][3] * scale);
+            w.y = quant4_rni_sat(x[c][4] * scale, x[c][5] * scale, x[c][6] * scale, x[c][7] * scale);
+            __builtin_amdgcn_raw_buffer_store_b64(w, q_rs, (c * NT + threadIdx.x) * 8, 0, 0);
         }
+    }
+    else
+    {
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+            if ((c * NT + (int) threadIdx.x) * 8 < a.hidden)
+                NormIO<T>::store8(a.out, base + (c * NT + threadIdx.x) * 8, x[c]);
+    }
 }
 
 // any hidden size: scalar, re-reads the row (three or four passes served by L2)
@@ -292,16 +390,30 @@ template <typename T, int MODE>
 void launch_norm(const NormArgs& a, hipStream_t stream)
 {
     const dim3 grid(a.tokens), block(256);
-    if (a.hidden % 8 != 0 || a.hidden > 16384)
+    // threads per row: 128 up to 8192 columns, 256 above (<= 8 chunks of 8 elements per thread).  Measured at
+    // 16384 x 4096 fp16, dynamic scale: 64 threads 49.0 us, 128 threads 43.8 us, 256 threads 46.6 us -- the row
+    // width hardly matters, and neither did halving the VALU work of the quantisation (a plain torch copy of the same
+    // footprint reaches 5.8 TB/s, this kernel 4.6)
+    static const int lab_nt = getenv("MI355Q_NORM_NT") ? atoi(getenv("MI355Q_NORM_NT")) : 0;
+    const int nt = lab_nt ? lab_nt : (a.hidden <= 8192 ? 128 : 256);
+    const int vpt = (a.hidden + nt * 8 - 1) / (nt * 8);
+    if (a.hidden % 8 != 0 || a.hidden > 16384 || vpt > 8)
         hipLaunchKernelGGL((norm_quant_generic_kernel<T, MODE>), grid, block, 0, stream, a);
-    else if (a.hidden <= 2048)
-        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 1>), grid, block, 0, stream, a);
-    else if (a.hidden <= 4096)
-        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 2>), grid, block, 0, stream, a);
-    else if (a.hidden <= 8192)
-        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 4>), grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, 8>), grid, block, 0, stream, a);
+    {
+#define MQ_NORM_CASE(V, N)                                                                                             \
+    if (vpt <= V && nt == N)                                                                                           \
+    {                                                                                                                  \
+        hipLaunchKernelGGL((norm_quant_kernel<T, MODE, V, N>), grid, dim3(N), 0, stream, a);                          \
+        MQ_HIP(hipGetLastError());                                                                                     \
+        return;                                                                                                        \
+    }
+        MQ_NORM_CASE(1, 64) MQ_NORM_CASE(2, 64) MQ_NORM_CASE(3, 64) MQ_NORM_CASE(4, 64) MQ_NORM_CASE(6, 64) MQ_NORM_CASE(8, 64)
+        MQ_NORM_CASE(1, 128) MQ_NORM_CASE(2, 128) MQ_NORM_CASE(3, 128) MQ_NORM_CASE(4, 128) MQ_NORM_CASE(6, 128) MQ_NORM_CASE(8, 128)
+        MQ_NORM_CASE(1, 256) MQ_NORM_CASE(2, 256) MQ_NORM_CASE(3, 256) MQ_NORM_CASE(4, 256) MQ_NORM_CASE(6, 256) MQ_NORM_CASE(8, 256)
+#undef MQ_NORM_CASE
+        MQ_CHECK(false, "norm: no kernel for hidden %d with %d threads per row", a.hidden, nt);
+    }
     MQ_HIP(hipGetLastError());
 }
 
@@ -348,11 +460,9 @@ __global__ __launch_bounds__(256) void quantize_tensor_kernel(int8_t* dst, const
     {
         float x[8];
         NormIO<T>::load8(src, (size_t) c * 8, x);
-        uint32_t w[2] = {0, 0};
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            w[j >> 2] |= quant_rni_sat(x[j] * scale) << (8 * (j & 3));
-        *reinterpret_cast<uint2*>(dst + c * 8) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint2*>(dst + c * 8)
+            = make_uint2(quant4_rni_sat(x[0] * scale, x[1] * scale, x[2] * scale, x[3] * scale),
+                quant4_rni_sat(x[4] * scale, x[5] * scale, x[6] * scale, x[7] * scale));
     }
 }
 
