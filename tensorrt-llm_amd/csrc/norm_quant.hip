@@ -170,17 +170,17 @@ struct NormRaw
     norm_u32x4_t v[sizeof(T) == 4 ? 2 : 1];
 };
 
-template <typename T>
+template <typename T, int AUX = 0>
 __device__ __forceinline__ NormRaw<T> norm_load8_raw(__amdgpu_buffer_rsrc_t rs, int i0)
 {
     NormRaw<T> r;
     if constexpr (sizeof(T) == 4)
     {
-        r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 4, 0, 0);
-        r.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 4 + 16, 0, 0);
+        r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 4, 0, AUX);
+        r.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 4 + 16, 0, AUX);
     }
     else
-        r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 2, 0, 0);
+        r.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 2, 0, AUX);
     return r;
 }
 
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NT) void norm_quant_kernel(NormArgs a)
         NormRaw<T> raw[VPT];
 #pragma unroll
         for (int c = 0; c < VPT; ++c)
-            raw[c] = norm_load8_raw<T>(in_rs, (c * NT + threadIdx.x) * 8);
+            raw[c] = norm_load8_raw<T, 2>(in_rs, (c * NT + threadIdx.x) * 8); // nontemporal: read once
 #pragma unroll
         for (int c = 0; c < VPT; ++c)
         {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NT) void norm_quant_kernel(NormArgs a)
             norm_u32x2_t w;
             w.x = quant4_rni_sat(x[c][0] * scale, x[c][1] * scale, x[c][2] * scale, x[c][3] * scale);
             w.y = quant4_rni_sat(x[c][4] * scale, x[c][5] * scale, x[c][6] * scale, x[c][7] * scale);
-            __builtin_amdgcn_raw_buffer_store_b64(w, q_rs, (c * NT + threadIdx.x) * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(w, q_rs, (c * NT + threadIdx.x) * 8, 0, 2);
         }
     }
     else
