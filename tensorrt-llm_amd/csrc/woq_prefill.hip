@@ -16,11 +16,15 @@
 //     consumes exactly the values mi355q_weight_only_dequantize returns;
 //   * the activation tile [TM][k-tile] goes through an LDS double buffer filled by LDS-DMA
 //     (global_load_lds_dwordx4; the XOR swizzle is applied to the per-lane source address so that the
-//     16 rows x one 16-byte chunk of a ds_read_b128 fragment cover all 64 banks once);
+//     16 rows x one 16-byte chunk of a ds_read_b128 fragment cover all 64 banks once).  The DMA is issued from
+//     inline asm and the weight loads carry no branch, so tile kt + 1 really is in flight while tile kt is computed:
+//     with the builtin DMA (and the half-tile branch inside the weight loads) hipcc put s_waitcnt vmcnt(0) in front
+//     of every tile's first LDS read -- load, wait, compute, in series;
 //   * the dequantised weights are the MFMA *A* operand and the activations the *B* operand, so a lane
 //     ends up with 4 consecutive output columns of one row: 8-byte stores, bias fused.
 #include "woq_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace mi355q
 {
@@ -32,6 +36,16 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 constexpr int PF_WAVES = 4;
+
+// LDS-DMA from inline asm (see context_attn.hip): after __builtin_amdgcn_global_load_lds hipcc makes every following
+// LDS read wait for vmcnt(0), i.e. the compute of tile kt waited for the prefetch of tile kt + 1 that had just been
+// issued.  lds_off: wave-uniform LDS byte address; lane l's 16 bytes land at lds_off + 16 l.
+// The source is base (SGPR pair) + a 32-bit per-lane byte offset: half the address registers of a 64-bit pointer.
+__device__ __forceinline__ void pf_dma16(const void* base, uint32_t voff, uint32_t lds_off)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_off)
+                 : "memory", "m0");
+}
 
 struct PrefillPlan
 {
@@ -90,15 +104,14 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
 
     // ---- activation staging (LDS-DMA).  DMA d covers rows [d*ROWS_PER_DMA, +ROWS_PER_DMA); lane -> (row, stored chunk)
     const int drow = lane / CHUNKS, dchunk = lane % CHUNKS;
-    const uint16_t* asrc[DMA_PER_WAVE];
-    int achunk[DMA_PER_WAVE];
+    uint32_t aoff[DMA_PER_WAVE]; // byte offset of the lane's 16 bytes in tile 0, from a.act (host checks m * k * 2 < 4 GiB)
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i)
     {
         const int d = wave * DMA_PER_WAVE + i;
         const int row = d * ROWS_PER_DMA + drow;
-        achunk[i] = dchunk ^ sw(row);
-        asrc[i] = a.act + (size_t) min(m0 + row, a.m - 1) * a.k; // rows past m re-read the last row; never stored
+        // rows past m re-read the last row; never stored
+        aoff[i] = (uint32_t) min(m0 + row, a.m - 1) * (uint32_t) a.k * 2u + (dchunk ^ sw(row)) * 16;
     }
     // k range of this workgroup (split-K over grid.y); the int4 half tile belongs to the last split
     const bool half_tile = WBITS == 4 && (a.k & 127);
@@ -106,7 +119,9 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     const int per = (nk_all + a.ksplit - 1) / a.ksplit;
     const int kt_lo = blockIdx.y * per;
     const int nk = min(nk_all, kt_lo + per);
-    auto stage = [&](int kt, int buf)
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) (lds_void_t*) lds);
+    const uint16_t* act_base = a.act;
+    auto stage = [&](int kt, int buf) // a full tile
     {
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i)
@@ -114,11 +129,20 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
             const int d = wave * DMA_PER_WAVE + i;
             if (DMA_PER_TILE % PF_WAVES != 0 && d >= DMA_PER_TILE)
                 continue;
-            int kk = kt * KTILE + achunk[i] * 8;
-            if (kk >= a.k) // half tile: chunks past k are staged from a valid address and never read
-                kk = kt * KTILE;
-            __builtin_amdgcn_global_load_lds(
-                (gbl_void_t*) (asrc[i] + kk), (lds_void_t*) (lds + buf * BUF_BYTES + d * 1024), 16, 0, 0);
+            pf_dma16(act_base, aoff[i] + kt * (KTILE * 2), lds_base + buf * BUF_BYTES + d * 1024);
+        }
+    };
+    auto stage_half = [&](int kt, int buf) // the int4 half tile: chunks past k are staged from a valid address, never read
+    {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i)
+        {
+            const int d = wave * DMA_PER_WAVE + i;
+            if (DMA_PER_TILE % PF_WAVES != 0 && d >= DMA_PER_TILE)
+                continue;
+            const int achunk = dchunk ^ sw(d * ROWS_PER_DMA + drow);
+            const uint32_t back = achunk * 8 >= 64 ? achunk * 16 : 0;
+            pf_dma16(act_base, aoff[i] - back + kt * (KTILE * 2), lds_base + buf * BUF_BYTES + d * 1024);
         }
     };
 
@@ -130,22 +154,12 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     struct WTile
     {
         uint4 w[NB];
-        uint16_t s[NB][NSZ], z[NB][NSZ];
+        uint32_t s[NB][NSZ], z[NB][NSZ]; // 16-bit values, zero-extended
     };
-    auto load_w = [&](WTile& t, int kt)
+    auto load_sz = [&](WTile& t, int kt)
     {
-        const bool half = kt == a.ktiles; // 512-byte trailing half tile: 8 bytes per lane
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-        {
-            const uint8_t* run = run0 + (size_t) b * run_bytes;
-            if (half)
-            {
-                const uint2 hw = *reinterpret_cast<const uint2*>(run + (size_t) kt * 1024 + lane * 8);
-                t.w[b] = make_uint4(hw.x, hw.y, 0, 0);
-            }
-            else
-                t.w[b] = *reinterpret_cast<const uint4*>(run + (size_t) kt * 1024 + lane * 16);
 #pragma unroll
             for (int h = 0; h < NSZ; ++h)
             {
@@ -154,6 +168,36 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
                 t.s[b][h] = a.scales[si];
                 t.z[b][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
             }
+    };
+    auto load_w = [&](WTile& t, int kt) // a full tile: no branch between the loads
+    {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            t.w[b] = *reinterpret_cast<const uint4*>(run0 + (size_t) b * run_bytes + (size_t) kt * 1024 + lane * 16);
+        load_sz(t, kt);
+    };
+    auto load_w_half = [&](WTile& t, int kt) // the 512-byte trailing half tile of int4 with k % 128 == 64: 8 bytes per lane
+    {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+        {
+            const uint2 hw = *reinterpret_cast<const uint2*>(run0 + (size_t) b * run_bytes + (size_t) kt * 1024 + lane * 8);
+            t.w[b] = make_uint4(hw.x, hw.y, 0, 0);
+        }
+        load_sz(t, kt);
+    };
+    // "the loads into t have landed" for the compiler's own bookkeeping: placed right after the explicit
+    // s_waitcnt vmcnt(0) of a tile boundary.  Without it hipcc (which does not see that wait, and does not count the
+    // asm DMAs) puts a vmcnt in front of the tile's first use that also waits for part of the NEXT tile's prefetch.
+    auto landed = [&](WTile& t)
+    {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+        {
+            asm volatile("" : "+v"(t.w[b].x), "+v"(t.w[b].y), "+v"(t.w[b].z), "+v"(t.w[b].w));
+#pragma unroll
+            for (int h = 0; h < NSZ; ++h)
+                asm volatile("" : "+v"(t.s[b][h]), "+v"(t.z[b][h]));
         }
     };
 
@@ -170,13 +214,16 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     const int fsw = sw(frow);
     const uint8_t* frag_base = lds + frow * RB;
 
+    // full tiles [kt_lo, nfull) run in the ping-pong loop; the int4 half tile (if it falls into this split) afterwards
+    const int nfull = min(nk, a.ktiles);
     WTile wt[2];
-    if (kt_lo < nk)
+    if (kt_lo < nfull)
     {
         stage(kt_lo, 0);
         load_w(wt[0], kt_lo);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(wt[0]);
     __syncthreads();
 
     auto compute = [&](const WTile& t, int buf, int steps)
@@ -187,8 +234,8 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int h = 0; h < NSZ; ++h)
             {
-                s[b][h] = T16<T>::to_float(t.s[b][h]);
-                z[b][h] = T16<T>::to_float(t.z[b][h]);
+                s[b][h] = T16<T>::to_float((uint16_t) t.s[b][h]);
+                z[b][h] = T16<T>::to_float((uint16_t) t.z[b][h]);
             }
         const uint8_t* sa = frag_base + buf * BUF_BYTES;
 #pragma unroll
@@ -223,27 +270,39 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
         }
     };
 
-    for (int kt = kt_lo; kt < nk; kt += 2)
+    // one tile boundary: everything issued for the next tile (DMA and weights) has landed, all waves are done with
+    // the buffer that is staged next
+    auto boundary = [&](WTile& next)
     {
-        // even tile of the range: buffers 0
-        if (kt + 1 < nk)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(next);
+        __syncthreads();
+    };
+    for (int kt = kt_lo; kt < nfull; kt += 2)
+    {
+        if (kt + 1 < nfull)
         {
             stage(kt + 1, 1);
             load_w(wt[1], kt + 1);
         }
-        compute(wt[0], 0, (kt == a.ktiles) ? 2 : KSTEPS);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 >= nk)
+        compute(wt[0], 0, KSTEPS);
+        boundary(wt[1]);
+        if (kt + 1 >= nfull)
             break;
-        if (kt + 2 < nk)
+        if (kt + 2 < nfull)
         {
             stage(kt + 2, 0);
             load_w(wt[0], kt + 2);
         }
-        compute(wt[1], 1, (kt + 1 == a.ktiles) ? 2 : KSTEPS);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        compute(wt[1], 1, KSTEPS);
+        boundary(wt[0]);
+    }
+    if (WBITS == 4 && nk > nfull) // the half tile: both buffers are free after the last boundary
+    {
+        stage_half(a.ktiles, 0);
+        load_w_half(wt[0], a.ktiles);
+        boundary(wt[0]);
+        compute(wt[0], 0, 2);
     }
 
     // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
@@ -339,6 +398,8 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
     a.group = h.group;
     a.group_shift = h.group_shift;
     a.ktiles = h.ktiles;
+    MQ_CHECK((uint64_t) h.m * (uint64_t) h.k * 2 < (1ull << 32),
+        "activation matrix of %d x %d exceeds the prefill kernel's 32-bit byte offsets (4 GiB)", h.m, h.k);
     a.ksplit = h.slabs ? plan_prefill(h.m, h.n, h.k, h.int4 ? 4 : 8).ksplit : 1;
     a.slabs = h.slabs;
     const bool bf = h.bf16, i4 = h.int4, z = h.zeros != nullptr;
