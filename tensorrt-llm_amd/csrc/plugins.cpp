@@ -1346,9 +1346,10 @@ void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stre
     mi355q_weight_only_params q = p;
     char* ws = static_cast<char*>(p.workspace);
     size_t ws_bytes = p.workspace_bytes;
-    if (p.act_scale && p.m > 0)
+    if (p.act_scale && !woq_gemm_fuses_act_scale(p.m, p.n, p.k))
     {
-        // weightOnlyGroupwiseQuantMatmulPlugin.cpp:382-418: smoothed activations go to the workspace
+        // weightOnlyGroupwiseQuantMatmulPlugin.cpp:382-418: smoothed activations go to the workspace (the decode
+        // kernel, m <= 32, applies the scale while it stages the rows instead: one launch less)
         const size_t act_bytes = align_up((size_t) p.m * p.k * 2, 256);
         MQ_CHECK(ws && ws_bytes >= act_bytes, "workspace too small for the smoothed activations (%zu < %zu)", ws_bytes,
             act_bytes);

@@ -20,6 +20,7 @@ struct WoqArgs
     const uint16_t* scales;
     const uint16_t* zeros;
     const uint16_t* act;
+    const uint16_t* act_scale; // per-channel pre-quant scale [k] applied while the decode kernel stages the rows, or null
     const uint16_t* bias;
     uint16_t* out;
     float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1

@@ -289,7 +289,18 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
             float part = 0.f;
             if (valid)
             {
-                const uint4 x = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
+                uint4 x = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
+                if (a.act_scale)
+                {
+                    // AWQ pre-quant scale fused into the staging: act * scale rounded to T, the values the separate
+                    // mi355q_apply_per_channel_scale pass (preQuantScaleKernel.cu) would have written
+                    const uint4 sc = *reinterpret_cast<const uint4*>(a.act_scale + k_lo + v * 8);
+                    uint32_t* xp = reinterpret_cast<uint32_t*>(&x);
+                    const uint32_t* sp = reinterpret_cast<const uint32_t*>(&sc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xp[j] = pack2<T>(T16<T>::lo(xp[j]) * T16<T>::lo(sp[j]), T16<T>::hi(xp[j]) * T16<T>::hi(sp[j]));
+                }
                 *reinterpret_cast<uint4*>(a_lds + r * lds_stride + v * 16) = x;
                 if constexpr (WBITS == 4)
                 {
@@ -707,16 +718,22 @@ void woq_splitk_reduce(const float* slabs, const void* bias, void* out, int m, i
             (const uint16_t*) bias, (uint16_t*) out, m, n, ksplit);
 }
 
+// m <= 32 (or shapes the prefill GEMM does not take) run the decode kernel, which applies the pre-quant scale itself
+bool woq_gemm_fuses_act_scale(int m, int n, int k)
+{
+    static const int gemv_max_m = std::getenv("MI355Q_GEMV_MAX_M") ? atoi(std::getenv("MI355Q_GEMV_MAX_M")) : GEMV_MAX_M;
+    return !(m > gemv_max_m && woq_prefill_supported(m, n, k) && !std::getenv("MI355Q_NO_PREFILL"));
+}
+
 void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream)
 {
     WoqArgs a = make_args(p);
     MQ_CHECK(p.in, "null activation");
     if (p.m == 0)
         return;
-    MQ_CHECK(p.act_scale == nullptr, "pre-quant scale must be applied with mi355q_apply_per_channel_scale first");
-    static const int gemv_max_m = std::getenv("MI355Q_GEMV_MAX_M") ? atoi(std::getenv("MI355Q_GEMV_MAX_M")) : GEMV_MAX_M;
-    if (p.m > gemv_max_m && woq_prefill_supported(p.m, p.n, p.k) && !std::getenv("MI355Q_NO_PREFILL"))
+    if (!woq_gemm_fuses_act_scale(p.m, p.n, p.k))
     {
+        MQ_CHECK(p.act_scale == nullptr, "pre-quant scale must be applied with mi355q_apply_per_channel_scale first");
         // m > 64: dequantise-in-registers MFMA GEMM (woq_prefill.hip); the decode kernel below would
         // stream the weights once per 64 rows
         const int ks = woq_prefill_ksplit(p.m, p.n, p.k, p.weight_type);
@@ -730,6 +747,7 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
         MQ_HIP(hipGetLastError());
         return;
     }
+    a.act_scale = static_cast<const uint16_t*>(p.act_scale); // decode kernel: applied while the rows are staged
     a.ksplit = woq_choose_ksplit(p.m, p.n, p.k, p.weight_type);
     if (a.ksplit > 1)
     {
