@@ -29,6 +29,7 @@ struct WoqArgs
     int group_shift; // log2(group); 31 for per-channel (k >> 31 == 0)
     int ktiles; // full k-tiles: k / KTILE
     int ksplit;
+    int red_buffers; // decode kernel: cross-wave reduce buffers in rotation (2: one barrier per n-block; 1: two)
 };
 
 template <typename T>

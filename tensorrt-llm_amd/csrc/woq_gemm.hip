@@ -77,12 +77,6 @@ __device__ __forceinline__ f32x4_t gemv_step(const uint4& w, const uint4& av, fl
 
 // floats of the S1 table of a block: one per (64-row unit of its k range, row of its 16 * mc rows), rounded so the
 // activation slab behind it stays 16-byte aligned; sized for the finest unit (group size 64) whatever the group is
-// cross-wave reduce buffers: 2 x 16 KiB when a block handles 16 rows, 1 x 32 KiB when it handles 32
-__host__ __device__ constexpr int gemv_red_slots(int mc)
-{
-    return mc == 1 ? 2 : 1;
-}
-
 __host__ __device__ constexpr int gemv_s1_floats(int krange, int mc)
 {
     return ((krange + 63) / 64) * 16 * mc;
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
     constexpr int KTILE = Geo<WBITS>::KTILE;
     // LDS: red[RB][MC][NWAVES][64][4] floats | s1[units][16 * MC] floats | activation rows
-    constexpr int RB = gemv_red_slots(MC); // reduce buffers: two (one barrier per n-block) when they are small
+    const int RB = a.red_buffers;          // reduce buffers: two (one barrier per n-block) when LDS has the room
     constexpr int UNIT = KTILE / NSZ;      // k rows that share one (scale, zero): the granule of S1
     constexpr int RED_FLOATS = MC * NWAVES * 64 * 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -281,44 +275,67 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         const int vec_per_row = (k_hi - k_lo) / 8;           // multiple of 8 (k % 64 == 0)
         const int vpr_pad = (vec_per_row + VPU - 1) / VPU * VPU;
         const int total = rows * vpr_pad;
-        for (int base = tid - lane; base < total; base += NWAVES * 64)
+        // SB vectors per thread and trip, all loads first (clamped addresses, no branch): with one load per trip a
+        // block of 16 rows paid 8 L2 round trips one after the other (M = 16 at 4096 x 4096: 10 us against 5 at M = 1)
+        constexpr int SB = 4;
+        for (int base = tid - lane; base < total; base += SB * NWAVES * 64)
         {
-            const int i = base + lane;
-            const int r = i / vpr_pad, v = i - r * vpr_pad;
-            const bool valid = i < total && v < vec_per_row;
-            float part = 0.f;
-            if (valid)
+            uint4 x[SB], sc[SB];
+            int r[SB], v[SB];
+            bool valid[SB];
+#pragma unroll
+            for (int b = 0; b < SB; ++b)
             {
-                uint4 x = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + r) * a.k + k_lo + v * 8);
+                const int i = base + b * NWAVES * 64 + lane;
+                r[b] = i / vpr_pad;
+                v[b] = i - r[b] * vpr_pad;
+                valid[b] = i < total && v[b] < vec_per_row;
+                const int rc = valid[b] ? r[b] : 0, vc = valid[b] ? v[b] : 0;
+                x[b] = *reinterpret_cast<const uint4*>(a.act + (size_t) (m0 + rc) * a.k + k_lo + vc * 8);
+            }
+            if (a.act_scale)
+            {
+#pragma unroll
+                for (int b = 0; b < SB; ++b)
+                    sc[b] = *reinterpret_cast<const uint4*>(a.act_scale + k_lo + (valid[b] ? v[b] : 0) * 8);
+            }
+#pragma unroll
+            for (int b = 0; b < SB; ++b)
+            {
+                if (base + b * NWAVES * 64 >= total) // wave-uniform: nothing left in this trip
+                    break;
+                float part = 0.f;
                 if (a.act_scale)
                 {
                     // AWQ pre-quant scale fused into the staging: act * scale rounded to T, the values the separate
                     // mi355q_apply_per_channel_scale pass (preQuantScaleKernel.cu) would have written
-                    const uint4 sc = *reinterpret_cast<const uint4*>(a.act_scale + k_lo + v * 8);
-                    uint32_t* xp = reinterpret_cast<uint32_t*>(&x);
-                    const uint32_t* sp = reinterpret_cast<const uint32_t*>(&sc);
+                    uint32_t* xp = reinterpret_cast<uint32_t*>(&x[b]);
+                    const uint32_t* sp = reinterpret_cast<const uint32_t*>(&sc[b]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         xp[j] = pack2<T>(T16<T>::lo(xp[j]) * T16<T>::lo(sp[j]), T16<T>::hi(xp[j]) * T16<T>::hi(sp[j]));
                 }
-                *reinterpret_cast<uint4*>(a_lds + r * lds_stride + v * 16) = x;
+                if (valid[b])
+                {
+                    *reinterpret_cast<uint4*>(a_lds + r[b] * lds_stride + v[b] * 16) = x[b];
+                    if constexpr (WBITS == 4)
+                    {
+                        const uint32_t* xd = reinterpret_cast<const uint32_t*>(&x[b]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            part += T16<T>::to_float((uint16_t) (xd[j] & 0xffffu)) + T16<T>::to_float((uint16_t) (xd[j] >> 16));
+                    }
+                }
                 if constexpr (WBITS == 4)
                 {
-                    const uint32_t* xd = reinterpret_cast<const uint32_t*>(&x);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        part += T16<T>::to_float((uint16_t) (xd[j] & 0xffffu)) + T16<T>::to_float((uint16_t) (xd[j] >> 16));
+                    part += __shfl_xor(part, 1);
+                    part += __shfl_xor(part, 2);
+                    part += __shfl_xor(part, 4);
+                    if constexpr (VPU == 16)
+                        part += __shfl_xor(part, 8);
+                    if (valid[b] && (v[b] & (VPU - 1)) == 0)
+                        s1_lds[(v[b] / VPU) * (16 * MC) + r[b]] = part;
                 }
-            }
-            if constexpr (WBITS == 4)
-            {
-                part += __shfl_xor(part, 1);
-                part += __shfl_xor(part, 2);
-                part += __shfl_xor(part, 4);
-                if constexpr (VPU == 16)
-                    part += __shfl_xor(part, 8);
-                if (valid && (v & (VPU - 1)) == 0)
-                    s1_lds[(v / VPU) * (16 * MC) + r] = part;
             }
         }
         if constexpr (WBITS == 4) // rows past m: never stored, keep them finite
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
         // the slot with an LDS atomic and the last arriver sums the 16 partials.  Slower, 27.5 us against 24.9 at
         // 28672 x 8192: the reduction then always lands on the wave that is already last.)
         float* red_nb = red;
-        if constexpr (RB == 2)
+        if (RB == 2)
         {
             red_nb = red + (it & 1) * RED_FLOATS;
             ++it;
@@ -556,7 +573,7 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
 // Launch geometry of the decode kernel (see woq_gemv_kernel).
 struct GemvPlan
 {
-    int ksplit, nwaves, ngroups, mc;
+    int ksplit, nwaves, ngroups, mc, red_buffers;
     size_t lds_bytes;
 };
 
@@ -573,12 +590,12 @@ int gemv_mc(int m)
 constexpr int GEMV_CUS = 256;
 constexpr size_t GEMV_LDS_MAX = 160 * 1024 - 512;
 
-size_t gemv_lds_bytes(int m, int k, int ktile, int ktiles, int ksplit, int nwaves)
+size_t gemv_lds_bytes(int m, int k, int ktile, int ktiles, int ksplit, int nwaves, int red_buffers)
 {
     const int seg = (ktiles + std::max(1, ksplit) - 1) / std::max(1, ksplit);
     const int krange = seg * ktile + (k - ktiles * ktile); // + the int4 half tile
     const int mc = gemv_mc(m);
-    return (size_t) gemv_red_slots(mc) * mc * nwaves * 64 * 4 * sizeof(float) + (size_t) gemv_s1_floats(krange, mc) * sizeof(float)
+    return (size_t) red_buffers * mc * nwaves * 64 * 4 * sizeof(float) + (size_t) gemv_s1_floats(krange, mc) * sizeof(float)
         + (size_t) std::min(16 * mc, m) * (krange * 2 + 32);
 }
 
@@ -592,9 +609,17 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     p.nwaves = 16; // one 16-wave block per CU: all of a CU's waves finish an n-block together
     // k segments: (a) the activation slab of a segment must fit LDS, (b) when the n-blocks alone leave
     // most CUs idle, split K across blocks (fp32 slabs + a reduce launch, so only if really idle)
-    int ks = 1;
-    while (ks < ktiles && gemv_lds_bytes(m, k, ktile, ktiles, ks, p.nwaves) > GEMV_LDS_MAX)
-        ++ks;
+    // two reduce buffers (one barrier per n-block) unless a single one saves a k split, i.e. the fp32 slabs and the
+    // reduce launch (m = 16 at k = 4096: 128 KiB of rows + 32 KiB of buffers do not fit, + 16 KiB do)
+    auto min_split = [&](int rb)
+    {
+        int s = 1;
+        while (s < ktiles && gemv_lds_bytes(m, k, ktile, ktiles, s, p.nwaves, rb) > GEMV_LDS_MAX)
+            ++s;
+        return s;
+    };
+    p.red_buffers = (p.mc == 1 && min_split(2) == min_split(1)) ? 2 : 1;
+    int ks = min_split(p.red_buffers);
     const int wgs = nblocks * mchunks;
     if (wgs < GEMV_CUS / 2)
     {
@@ -608,7 +633,7 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     const int slots = std::max(1, GEMV_CUS / (mchunks * p.ksplit));
     const int iters = (nblocks + slots - 1) / slots;
     p.ngroups = (nblocks + iters - 1) / iters;
-    p.lds_bytes = gemv_lds_bytes(m, k, ktile, ktiles, p.ksplit, p.nwaves);
+    p.lds_bytes = gemv_lds_bytes(m, k, ktile, ktiles, p.ksplit, p.nwaves, p.red_buffers);
     MQ_CHECK(p.lds_bytes <= GEMV_LDS_MAX, "k=%d too large for the decode kernel's LDS activation slab", k);
     return p;
 }
@@ -637,24 +662,27 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
     if (a.ksplit != p.ksplit) // no workspace for the slabs: one segment (must still fit LDS)
     {
         q.ksplit = 1;
-        q.lds_bytes = gemv_lds_bytes(a.m, a.k, Geo<WBITS>::KTILE, a.ktiles, 1, p.nwaves);
+        q.red_buffers = 1;
+        q.lds_bytes = gemv_lds_bytes(a.m, a.k, Geo<WBITS>::KTILE, a.ktiles, 1, p.nwaves, 1);
         MQ_CHECK(q.lds_bytes <= GEMV_LDS_MAX,
             "this m/k needs the split-K workspace (mi355q_weight_only_gemm_workspace_size)");
     }
+    WoqArgs ka = a;
+    ka.red_buffers = q.red_buffers;
     dim3 grid(q.ngroups, (a.m + 16 * q.mc - 1) / (16 * q.mc), q.ksplit);
     // ring geometry: 3 register images of 2 tiles (measured best of {2x4, 3x4, 4x2, 6x2, 3x2, 4x1, 6x1, 8x1} at
     // 28672 x 8192 and no worse elsewhere); MI355Q_GEMV_RING = 10 * images + tiles selects the lab alternatives
     static const int lab = getenv("MI355Q_GEMV_RING") ? atoi(getenv("MI355Q_GEMV_RING")) : 0;
     if (q.mc == 2 && lab == 32)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 3>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 3>(ka, grid, q.lds_bytes, stream);
     else if (q.mc == 2)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 2>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 2>(ka, grid, q.lds_bytes, stream);
     else if (lab == 24)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 4, 1, 2>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 4, 1, 2>(ka, grid, q.lds_bytes, stream);
     else if (lab == 41)
-        launch_gemv_variant<T, WBITS, ZERO, 16, 1, 1, 4>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 1, 1, 4>(ka, grid, q.lds_bytes, stream);
     else
-        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 1, 3>(a, grid, q.lds_bytes, stream);
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 1, 3>(ka, grid, q.lds_bytes, stream);
     if (a.ksplit > 1)
     {
         const size_t total = (size_t) a.m * a.n;
