@@ -66,6 +66,50 @@ __device__ __forceinline__ void store_out(void* C, int out_type, size_t idx, flo
 }
 
 // 128 x 128 output tile, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
+
+// four consecutive outputs of one row -> C in the requested type (OUT is a compile-time copy of g.out_type: the
+// epilogue loops are instantiated once per type instead of switching per fragment)
+template <int OUT>
+__device__ __forceinline__ void gemm8_store4(void* C, size_t idx, const float (&v)[4])
+{
+    if constexpr (OUT == MI355Q_HALF)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(C) + idx)
+            = make_uint2(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]));
+    else if constexpr (OUT == MI355Q_BF16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(C) + idx)
+            = make_uint2(pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3]));
+    else if constexpr (OUT == MI355Q_FLOAT)
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+        *reinterpret_cast<int4*>(reinterpret_cast<int32_t*>(C) + idx)
+            = make_int4((int) rintf(v[0]), (int) rintf(v[1]), (int) rintf(v[2]), (int) rintf(v[3]));
+}
+
+// the lane's 4 consecutive per-channel scales at column `col` (one 16-byte load), or the per-tensor scale four times
+__device__ __forceinline__ void gemm8_col_scales(const Gemm8Args& g, size_t col, float (&sc)[4])
+{
+    if (g.per_channel)
+    {
+        const float4 t = *reinterpret_cast<const float4*>(g.alpha_col + col);
+        sc[0] = t.x, sc[1] = t.y, sc[2] = t.z, sc[3] = t.w;
+    }
+    else
+        sc[0] = sc[1] = sc[2] = sc[3] = g.alpha_col[0];
+}
+
+// runs body(std::integral_constant<int, out_type>)
+template <typename F>
+__device__ __forceinline__ void gemm8_dispatch_out(int out_type, F body)
+{
+    switch (out_type)
+    {
+    case MI355Q_HALF: body(std::integral_constant<int, MI355Q_HALF>{}); break;
+    case MI355Q_BF16: body(std::integral_constant<int, MI355Q_BF16>{}); break;
+    case MI355Q_FLOAT: body(std::integral_constant<int, MI355Q_FLOAT>{}); break;
+    default: body(std::integral_constant<int, MI355Q_INT32>{}); break;
+    }
+}
+
 template <bool FP8>
 __global__ __launch_bounds__(256) void gemm8_kernel(Gemm8Args g)
 {
@@ -317,42 +361,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm8_big_kernel(Gemm8Args g, in
         __syncthreads();
     }
 
-    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
+    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.  All scale loads first: with the
+    // loads inside the fragment loop every fragment paid an L2 round trip before its store (nothing else runs on
+    // the CU at that point).
     const int em = lane & 15, en = (lane >> 4) * 4;
+    float sr[MT], sc[NT][4];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
+        sr[j] = g.alpha_row[g.per_token ? m0 + wm * WTM + j * 16 + em : 0];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        gemm8_col_scales(g, n0 + wn * WTN + i * 16 + en, sc[i]);
+    gemm8_dispatch_out(g.out_type, [&](auto out)
     {
-        const size_t row = m0 + wm * WTM + j * 16 + em;
-        const float sr = g.alpha_row[g.per_token ? row : 0];
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int j = 0; j < MT; ++j)
         {
-            const size_t col = n0 + wn * WTN + i * 16 + en;
-            float v[4];
+            const size_t row = m0 + wm * WTM + j * 16 + em;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = (float) acc[i][j][r] * (g.alpha_col[g.per_channel ? col + r : 0] * sr);
-            const size_t idx = row * g.ldc + col;
-            switch (g.out_type)
+            for (int i = 0; i < NT; ++i)
             {
-            case MI355Q_HALF:
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
-                    = make_uint2(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]));
-                break;
-            case MI355Q_BF16:
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
-                    = make_uint2(pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3]));
-                break;
-            case MI355Q_FLOAT:
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + idx) = make_float4(v[0], v[1], v[2], v[3]);
-                break;
-            default:
-                *reinterpret_cast<int4*>(reinterpret_cast<int32_t*>(g.C) + idx)
-                    = make_int4((int) rintf(v[0]), (int) rintf(v[1]), (int) rintf(v[2]), (int) rintf(v[3]));
-                break;
+                const size_t col = n0 + wn * WTN + i * 16 + en;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (float) acc[i][j][r] * (sc[i][r] * sr[j]);
+                gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
             }
         }
-    }
+    });
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -584,42 +621,34 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
 #undef P8_WAIT_VM6
 #undef P8_WAIT_LGKM0
 
-    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
+    // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.  All scale loads first (see
+    // gemm8_big_kernel).
     const int em = lane & 15, en = (lane >> 4) * 4;
+    float sr[8], sc[4][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
+        sr[i] = g.alpha_row[g.per_token ? m0 + wr * 128 + i * 16 + em : 0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        gemm8_col_scales(g, n0 + wc * 64 + j * 16 + en, sc[j]);
+    gemm8_dispatch_out(g.out_type, [&](auto out)
     {
-        const size_t row = m0 + wr * 128 + i * 16 + em;
-        const float sr = g.alpha_row[g.per_token ? row : 0];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 8; ++i)
         {
-            const size_t col = n0 + wc * 64 + j * 16 + en;
-            float v[4];
+            const size_t row = m0 + wr * 128 + i * 16 + em;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = (float) acc[i][j][r] * (g.alpha_col[g.per_channel ? col + r : 0] * sr);
-            const size_t idx = row * g.ldc + col;
-            switch (g.out_type)
+            for (int j = 0; j < 4; ++j)
             {
-            case MI355Q_HALF:
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
-                    = make_uint2(pack2<f16_t>(v[0], v[1]), pack2<f16_t>(v[2], v[3]));
-                break;
-            case MI355Q_BF16:
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(g.C) + idx)
-                    = make_uint2(pack2<bf16_t>(v[0], v[1]), pack2<bf16_t>(v[2], v[3]));
-                break;
-            case MI355Q_FLOAT:
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + idx) = make_float4(v[0], v[1], v[2], v[3]);
-                break;
-            default:
-                *reinterpret_cast<int4*>(reinterpret_cast<int32_t*>(g.C) + idx)
-                    = make_int4((int) rintf(v[0]), (int) rintf(v[1]), (int) rintf(v[2]), (int) rintf(v[3]));
-                break;
+                const size_t col = n0 + wc * 64 + j * 16 + en;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (float) acc[i][j][r] * (sc[j][r] * sr[i]);
+                gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
             }
         }
-    }
+    });
 }
 
 template <bool FP8>
