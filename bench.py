@@ -270,6 +270,49 @@ def bench_rmsnorm_quant(dev, steps, tokens=4096, hidden=5120, sets=24):
             "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo}
 
 
+def bench_gated_act(dev, steps, tokens=4096, inter=13824, sets=6):
+    """8f rank 2: silu(fc) * gate / smoother + dynamic per-token int8 quantisation in one pass (the feeder of the cfg3
+    down projection, Llama-2-13B intermediate size), and the plain one-pass per-token quantisation (a10).
+    Algorithmic bytes: tokens*inter*(2 + 2 in + 1 out) resp. tokens*inter*(2 + 1)."""
+    from mi355q import _lib as L
+    import ctypes as C
+    torch.manual_seed(0)
+    gu = [torch.randn(tokens, 2 * inter, device=dev).to(torch.float16) for _ in range(sets)]
+    smoother = (torch.rand(inter, device=dev) + 0.5).to(torch.float16)
+    q = torch.empty(tokens, inter, dtype=torch.int8, device=dev)
+    sc = torch.empty(tokens, 1, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    params = []
+    for t in gu:
+        p = L.GatedActParams()
+        p.act_in, p.gate_in, p.smoother = t.data_ptr(), t.data_ptr() + inter * 2, smoother.data_ptr()
+        p.out_quant, p.dynamic_scale = q.data_ptr(), sc.data_ptr()
+        p.rows, p.cols, p.ld_act, p.ld_gate, p.type = tokens, inter, 2 * inter, 2 * inter, L.HALF
+        params.append(p)
+    it = [0]
+
+    def step_gated():
+        assert L.lib().mi355q_gated_silu(C.byref(params[it[0] % sets]), stream) == 0
+        it[0] += 1
+
+    def step_ptq():  # the first `inter` columns of every row: a [tokens, inter] matrix needs a dense source
+        assert L.lib().mi355q_per_token_quantization(q.data_ptr(), dense[it[0] % sets].data_ptr(), tokens, inter,
+                                                     sc.data_ptr(), L.HALF, stream) == 0
+        it[0] += 1
+    _, dev_s = time_steps(step_gated, steps, sets, lambda: None)
+    algo = tokens * inter * 5 + inter * 2 + tokens * 4
+    out = [{"op": "silu(fc)*gate/smoother + per-token int8", "tokens": tokens, "cols": inter, "us_per_call": dev_s / steps * 1e6,
+            "GBps": algo / (dev_s / steps) / 1e9, "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": algo}]
+    dense = [t.view(2 * tokens, inter)[:tokens] for t in gu]
+    _, dev_s = time_steps(step_ptq, steps, sets, lambda: None)
+    algo = tokens * inter * 3 + tokens * 4
+    out.append({"op": "per-token int8 quantisation", "tokens": tokens, "cols": inter, "us_per_call": dev_s / steps * 1e6,
+                "GBps": algo / (dev_s / steps) / 1e9, "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes": algo})
+    return out
+
+
 def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16"):
     """8f rank 1: context (prefill) attention, Llama-2-7B heads: bias-less RoPE + paged KV append + causal
     attention; flops counted on the causal half (2 * 2 * S^2/2 * D per head)."""
@@ -417,6 +460,7 @@ def main():
                 sec["int8_gemm"] = [bench_int8_gemm(dev, 10), bench_int8_gemm(dev, 10, n=5120, k=13824)]
                 sec["fp8_gemm"] = [bench_fp8_gemm(dev, 10), bench_fp8_gemm(dev, 10, n=4096, k=14336)]
                 sec["rmsnorm_quant"] = [bench_rmsnorm_quant(dev, 96), bench_rmsnorm_quant(dev, 96, hidden=8192, sets=16)]
+                sec["gated_act_quant"] = bench_gated_act(dev, 48)
                 sec["context_attention"] = [bench_context_attention(dev, 10),
                                             bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8")]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]

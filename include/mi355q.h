@@ -221,6 +221,28 @@ extern "C"
     mi355q_status mi355q_quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scalePtr,
         int32_t src_type, void* stream);
 
+    /* The gated activation of the SmoothQuant MLP between the gate/up GEMMs and the down projection, in one pass:
+     * tensorrt_llm/quantization/layers.py:922-941 SmoothQuantGatedMLP.forward (inter = silu(fc(x)); y = inter * gate(x);
+     * y = y / smoother; quantize_tensor(y, scale) | quantize_per_token(y)) and tensorrt_llm/functional.py:736-752 swiglu
+     * (the fused [rows, 2 * cols] layout: gate_in = input, act_in = input + cols, both strides 2 * cols).  Every step
+     * is rounded to T like the reference's layer boundaries.  out (T) and/or out_quant (int8): with dynamic_scale the
+     * row is quantised with 127 / amax(row) and dynamic_scale[row] = amax / 127 (quantization.cu:93-127), else with
+     * scale != NULL by *scale (quantization.cu:30-86); smoother may be NULL.  cols % 8 == 0, cols <= 32768. */
+    typedef struct mi355q_gated_act_params
+    {
+        const void* act_in;   /* T [rows, cols], row stride ld_act elements: goes through SiLU */
+        const void* gate_in;  /* T [rows, cols], row stride ld_gate elements: the multiplier */
+        const void* smoother; /* T [cols] or NULL */
+        void* out;            /* T [rows, cols] or NULL */
+        int8_t* out_quant;    /* int8 [rows, cols] or NULL */
+        const float* scale;   /* static per-tensor scale or NULL */
+        float* dynamic_scale; /* fp32 [rows] out, or NULL */
+        int32_t rows, cols;
+        int64_t ld_act, ld_gate;
+        int32_t type; /* MI355Q_FLOAT / MI355Q_HALF / MI355Q_BF16 */
+    } mi355q_gated_act_params;
+    mi355q_status mi355q_gated_silu(const mi355q_gated_act_params* params, void* stream);
+
     /* kernels/rmsnormKernels.cu:176-206 invokeGeneralRmsNorm(out, input, gamma, beta, eps, tokens, hidden_dim, stream,
      * scale, dynamic_scale, normed_output_quant): out = T(x * rsqrt(mean(x^2) + eps) * gamma + beta); with
      * dynamic_scale != NULL the row is quantised with 127 / amax(row) and dynamic_scale[row] = amax / 127, else with

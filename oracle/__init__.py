@@ -542,6 +542,28 @@ def norm_quant(x, gamma, beta, eps, kind="rms", scale=None, dynamic=False, use_d
     return val.reshape(x.shape), None
 
 
+def gated_silu(act_in, gate_in, smoother=None, scale=None, dynamic=False):
+    """SmoothQuantGatedMLP.forward (tensorrt_llm/quantization/layers.py:922-941) between fc / gate and proj, restated
+    with one rounding to T per layer of the reference's graph: inter = T(silu(act_in)) (silu evaluated in fp32),
+    y = T(inter * gate_in), y = T(y / smoother); then quantize_tensor (static scale: rni_sat(y * scale),
+    quantization.cu:30-86), quantize_per_token (dynamic: amax = max(|y|, T(1e-6)), rni_sat(y * (127 / amax)), scales =
+    amax / 127, quantization.cu:93-127), or y.  functional.swiglu (functional.py:736-752) is the same product with
+    act_in / gate_in = the two halves of one tensor and no smoother.  Returns (out, scales-or-None)."""
+    T = act_in.dtype
+    a = act_in.float()
+    y = (a / (1.0 + torch.exp(-a))).to(T)
+    y = (y.float() * gate_in.float()).to(T)
+    if smoother is not None:
+        y = (y.float() / smoother.float()).to(T)
+    if dynamic:
+        floor = torch.tensor(1e-6, dtype=torch.float32).to(T).float()
+        amax = torch.maximum(y.float().abs().amax(-1, keepdim=True), floor)
+        return cast_int8_rni_sat(y.float() * (np.float32(127.0) / amax)), amax / np.float32(127.0)
+    if scale is not None:
+        return cast_int8_rni_sat(y.float() * np.float32(scale)), None
+    return y, None
+
+
 # ----------------------------------------------------------------------------- custom all-reduce
 def _add_T(a, b):
     """One add in T arithmetic: fp32 add of the widened operands, one rounding to T (half2 / bfloat162 add)."""

@@ -953,6 +953,14 @@ void per_token_quantization(
     MQ_CHECK(dst && src && scales, "null tensor");
     if (rows == 0)
         return;
+    static const bool lab_scalar = getenv("MI355Q_PTQ_SCALAR") != nullptr; // lab: the two-pass scalar kernel below
+    if (row_quant_supported(cols) && !lab_scalar
+        && (src_type == MI355Q_FLOAT || src_type == MI355Q_HALF || src_type == MI355Q_BF16))
+    {
+        // one pass, the row in registers (norm_quant.hip): the same arithmetic as the kernel below
+        per_token_quantization_rows(dst, src, rows, cols, scales, src_type, stream);
+        return;
+    }
     // T(1e-6f) rounded to the source type, as `T localMax = 1e-6f` does
     switch (src_type)
     {

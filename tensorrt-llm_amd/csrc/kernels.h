@@ -55,6 +55,9 @@ void rms_norm(void* out, const void* input, const void* gamma, const void* beta,
 void layer_norm(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens, int hidden,
     bool use_diff_of_squares, const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream);
 void quantize_tensor(int8_t* dst, const void* src, int64_t size, const float* scale, int type, hipStream_t stream);
+bool row_quant_supported(int64_t cols);
+void per_token_quantization_rows(int8_t* dst, const void* src, int64_t rows, int64_t cols, float* scales, int type, hipStream_t stream);
+void gated_silu(const mi355q_gated_act_params& p, hipStream_t stream);
 
 // allreduce.hip
 void allreduce_params_deserialize(

@@ -322,6 +322,132 @@ __global__ __launch_bounds__(NT) void norm_quant_kernel(NormArgs a)
     }
 }
 
+
+// ---- row kernel without statistics: per-token int8 quantisation of x itself (OP 0; quantization.cu:93-127
+// invokePerTokenQuantization) or of the gated activation of the SmoothQuant MLP (OP 1; quantization/layers.py:922-941
+// SmoothQuantGatedMLP.forward: inter = silu(fc(x)); y = inter * gate(x); y = y / smoother; quantize_tensor |
+// quantize_per_token), every step rounded to T as the reference's layer boundaries do.  Same layout as the norm
+// kernel: the row stays in registers between the amax and the output, one read and one write per element.
+struct RowQuantArgs
+{
+    const void* x;        // [rows, cols], row stride ld_x elements; OP 1: the tensor that goes through SiLU
+    const void* gate;     // OP 1: the multiplier, row stride ld_gate
+    const void* smoother; // OP 1: T [cols] divisor, or null
+    void* out;            // T [rows, cols] or null
+    int8_t* out_quant;    // int8 [rows, cols] or null
+    const float* scale_per_tensor;
+    float* scale_per_token;
+    int rows, cols;
+    int64_t ld_x, ld_gate;
+};
+
+template <typename T, int OP, int VPT, int NT>
+__global__ __launch_bounds__(NT) void row_quant_kernel(RowQuantArgs a)
+{
+    __shared__ float sm[4];
+    const size_t row = blockIdx.x;
+    const uint32_t row_bytes = (uint32_t) a.cols * sizeof(T);
+    const __amdgpu_buffer_rsrc_t x_rs = norm_rsrc(static_cast<const char*>(a.x) + row * a.ld_x * sizeof(T), row_bytes);
+    float x[VPT][8];
+    {
+        NormRaw<T> raw[VPT];
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+            raw[c] = norm_load8_raw<T, 2>(x_rs, (c * NT + threadIdx.x) * 8);
+        if constexpr (OP == 1)
+        {
+            const __amdgpu_buffer_rsrc_t g_rs
+                = norm_rsrc(static_cast<const char*>(a.gate) + row * a.ld_gate * sizeof(T), row_bytes);
+            const __amdgpu_buffer_rsrc_t s_rs = norm_rsrc(a.smoother ? a.smoother : a.x, a.smoother ? row_bytes : 0);
+            NormRaw<T> graw[VPT], sraw[VPT];
+#pragma unroll
+            for (int c = 0; c < VPT; ++c)
+                graw[c] = norm_load8_raw<T, 2>(g_rs, (c * NT + threadIdx.x) * 8);
+#pragma unroll
+            for (int c = 0; c < VPT; ++c)
+                sraw[c] = norm_load8_raw<T>(s_rs, (c * NT + threadIdx.x) * 8);
+#pragma unroll
+            for (int c = 0; c < VPT; ++c)
+            {
+                float g[8], sd[8];
+                norm_cvt8<T>(raw[c], x[c]);
+                norm_cvt8<T>(graw[c], g);
+                norm_cvt8<T>(sraw[c], sd);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                {
+                    // silu(v) = v / (1 + exp(-v)); elements past the row are 0 -> 0
+                    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x[c][j]);
+                    float v = NormIO<T>::round(x[c][j] * __builtin_amdgcn_rcpf(1.f + e));
+                    v = NormIO<T>::round(v * g[j]);
+                    if (a.smoother)
+                        v = NormIO<T>::round(v * __builtin_amdgcn_rcpf(sd[j]));
+                    x[c][j] = v;
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int c = 0; c < VPT; ++c)
+                norm_cvt8<T>(raw[c], x[c]);
+        }
+    }
+    float scale = 0.f;
+    if (a.scale_per_token)
+    {
+        float amax = NormIO<T>::round(1e-6f);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                amax = fmaxf(amax, fabsf(x[c][j]));
+        amax = block_reduce<true, NT>(amax, sm);
+        scale = 127.f / amax;
+        if (threadIdx.x == 0)
+            a.scale_per_token[row] = amax / 127.f;
+    }
+    else if (a.scale_per_tensor)
+        scale = a.scale_per_tensor[0];
+    if (a.out_quant)
+    {
+        const __amdgpu_buffer_rsrc_t q_rs = norm_rsrc(a.out_quant + row * a.cols, (uint32_t) a.cols);
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+        {
+            norm_u32x2_t w;
+            w.x = quant4_rni_sat(x[c][0] * scale, x[c][1] * scale, x[c][2] * scale, x[c][3] * scale);
+            w.y = quant4_rni_sat(x[c][4] * scale, x[c][5] * scale, x[c][6] * scale, x[c][7] * scale);
+            __builtin_amdgcn_raw_buffer_store_b64(w, q_rs, (c * NT + threadIdx.x) * 8, 0, 2);
+        }
+    }
+    if (a.out)
+    {
+#pragma unroll
+        for (int c = 0; c < VPT; ++c)
+            if ((c * NT + (int) threadIdx.x) * 8 < a.cols)
+                NormIO<T>::store8(a.out, row * a.cols + (c * NT + threadIdx.x) * 8, x[c]);
+    }
+}
+
+template <typename T, int OP>
+void launch_row_quant(const RowQuantArgs& a, hipStream_t stream)
+{
+    const int nt = a.cols <= 8192 ? 128 : 256;
+    const int vpt = (a.cols + nt * 8 - 1) / (nt * 8);
+#define MQ_ROW_CASE(V, N)                                                                                              \
+    if (vpt <= V && nt == N)                                                                                           \
+    {                                                                                                                  \
+        hipLaunchKernelGGL((row_quant_kernel<T, OP, V, N>), dim3(a.rows), dim3(N), 0, stream, a);                     \
+        MQ_HIP(hipGetLastError());                                                                                     \
+        return;                                                                                                        \
+    }
+    MQ_ROW_CASE(1, 128) MQ_ROW_CASE(2, 128) MQ_ROW_CASE(3, 128) MQ_ROW_CASE(4, 128) MQ_ROW_CASE(6, 128) MQ_ROW_CASE(8, 128)
+    MQ_ROW_CASE(6, 256) MQ_ROW_CASE(8, 256) MQ_ROW_CASE(12, 256) MQ_ROW_CASE(16, 256)
+#undef MQ_ROW_CASE
+    MQ_CHECK(false, "row kernel: %d columns exceed 32768", a.cols);
+}
+
 // any hidden size: scalar, re-reads the row (three or four passes served by L2)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void norm_quant_generic_kernel(NormArgs a)
@@ -489,6 +615,63 @@ void launch_quantize_tensor(int8_t* dst, const void* src, int64_t size, const fl
 }
 
 } // namespace
+
+bool row_quant_supported(int64_t cols)
+{
+    return cols % 8 == 0 && cols > 0 && cols <= 32768;
+}
+
+void per_token_quantization_rows(int8_t* dst, const void* src, int64_t rows, int64_t cols, float* scales, int type, hipStream_t stream)
+{
+    RowQuantArgs a{};
+    a.x = src;
+    a.out_quant = dst;
+    a.scale_per_token = scales;
+    a.rows = (int) rows;
+    a.cols = (int) cols;
+    a.ld_x = cols;
+    switch (type)
+    {
+    case MI355Q_FLOAT: launch_row_quant<float, 0>(a, stream); break;
+    case MI355Q_HALF: launch_row_quant<f16_t, 0>(a, stream); break;
+    case MI355Q_BF16: launch_row_quant<bf16_t, 0>(a, stream); break;
+    default: MQ_CHECK(false, "per-token quantisation of dtype %d", type);
+    }
+}
+
+void gated_silu(const mi355q_gated_act_params& p, hipStream_t stream)
+{
+    MQ_CHECK(p.rows >= 0 && p.cols > 0, "rows %d cols %d", p.rows, p.cols);
+    if (p.rows == 0)
+        return;
+    MQ_CHECK(p.act_in && p.gate_in, "null input");
+    MQ_CHECK(p.cols % 8 == 0 && p.cols <= 32768, "cols must be a multiple of 8 and <= 32768, got %d", p.cols);
+    MQ_CHECK(p.ld_act >= p.cols && p.ld_gate >= p.cols && p.ld_act % 8 == 0 && p.ld_gate % 8 == 0,
+        "row strides must be >= cols and multiples of 8 elements");
+    if (p.scale || p.dynamic_scale)
+        MQ_CHECK(p.out_quant, "a quantised output buffer is needed with scale / dynamic_scale");
+    else
+        MQ_CHECK(p.out, "null output");
+    RowQuantArgs a{};
+    a.x = p.act_in;
+    a.gate = p.gate_in;
+    a.smoother = p.smoother;
+    a.out = p.out;
+    a.out_quant = (p.scale || p.dynamic_scale) ? p.out_quant : nullptr;
+    a.scale_per_tensor = p.dynamic_scale ? nullptr : p.scale;
+    a.scale_per_token = p.dynamic_scale;
+    a.rows = p.rows;
+    a.cols = p.cols;
+    a.ld_x = p.ld_act;
+    a.ld_gate = p.ld_gate;
+    switch (p.type)
+    {
+    case MI355Q_FLOAT: launch_row_quant<float, 1>(a, stream); break;
+    case MI355Q_HALF: launch_row_quant<f16_t, 1>(a, stream); break;
+    case MI355Q_BF16: launch_row_quant<bf16_t, 1>(a, stream); break;
+    default: MQ_CHECK(false, "gated activation: unsupported data type %d (float, half, bf16)", p.type);
+    }
+}
 
 void rms_norm(void* out, const void* input, const void* gamma, const void* beta, float eps, int tokens, int hidden,
     const float* scale, float* dynamic_scale, int8_t* out_quant, int type, hipStream_t stream)

@@ -1630,6 +1630,16 @@ extern "C"
         return guarded([&] { quantize_tensor(dst, src, size, scalePtr, src_type, static_cast<hipStream_t>(stream)); });
     }
 
+    mi355q_status mi355q_gated_silu(const mi355q_gated_act_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null params");
+                gated_silu(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
     mi355q_status mi355q_rms_norm(void* out, const void* input, const void* gamma, const void* beta, float eps,
         int32_t tokens, int32_t hidden_dim, const float* scale, float* dynamic_scale, int8_t* normed_output_quant,
         int32_t type, void* stream)

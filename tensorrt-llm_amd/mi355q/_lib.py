@@ -112,6 +112,14 @@ class AllReduceParams(C.Structure):
     ]
 
 
+class GatedActParams(C.Structure):
+    _fields_ = [
+        ("act_in", C.c_void_p), ("gate_in", C.c_void_p), ("smoother", C.c_void_p), ("out", C.c_void_p),
+        ("out_quant", C.c_void_p), ("scale", C.c_void_p), ("dynamic_scale", C.c_void_p),
+        ("rows", C.c_int32), ("cols", C.c_int32), ("ld_act", C.c_int64), ("ld_gate", C.c_int64), ("type", C.c_int32),
+    ]
+
+
 class Mi355qError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"mi355q status {status}: {msg}")
@@ -153,6 +161,7 @@ SYMBOLS = {
     "mi355q_int8_gemm": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_per_token_quantization": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp]),
     "mi355q_quantize_tensor": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
+    "mi355q_gated_silu": (_i32, [_vp, _vp]),
     "mi355q_rms_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mi355q_layer_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mi355q_fp8_gemm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

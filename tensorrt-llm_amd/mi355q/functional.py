@@ -217,6 +217,45 @@ def layer_norm(input, weight, bias=None, eps=1e-05, use_diff_of_squares=True):
     return out
 
 
+def gated_silu(act_in, gate_in, smoother=None, scale=None, dynamic_act_scaling=False):
+    """SmoothQuantGatedMLP.forward between the gate/up GEMMs and the down projection (quantization/layers.py:922-941):
+    y = T(T(T(silu(act_in)) * gate_in) / smoother), then quantize_tensor(y, scale) (static), quantize_per_token(y)
+    (dynamic: returns (int8, scales [..., 1])), or y itself.  act_in / gate_in: [..., cols] views whose last dimension
+    is contiguous (row strides may differ: the two halves of a fused gate|up GEMM output are fine)."""
+    cols = act_in.shape[-1]
+    a2, g2 = act_in.reshape(-1, cols), gate_in.reshape(-1, cols)
+    assert a2.stride(-1) == 1 and g2.stride(-1) == 1
+    rows = a2.shape[0]
+    p = L.GatedActParams()
+    p.act_in, p.gate_in = a2.data_ptr(), g2.data_ptr()
+    p.ld_act, p.ld_gate = (a2.stride(0) if rows > 1 else cols), (g2.stride(0) if rows > 1 else cols)
+    p.smoother = smoother.data_ptr() if smoother is not None else None
+    p.rows, p.cols, p.type = rows, cols, torch_dtype_to_trt(act_in.dtype)
+    out = q = scales = None
+    if dynamic_act_scaling or scale is not None:
+        q = torch.empty(list(act_in.shape), dtype=torch.int8, device=act_in.device)
+        p.out_quant = q.data_ptr()
+        if dynamic_act_scaling:
+            scales = torch.empty(list(act_in.shape[:-1]) + [1], dtype=torch.float32, device=act_in.device)
+            p.dynamic_scale = scales.data_ptr()
+        else:
+            scale = scale.to(torch.float32).contiguous()
+            p.scale = scale.data_ptr()
+    else:
+        out = torch.empty(list(act_in.shape), dtype=act_in.dtype, device=act_in.device)
+        p.out = out.data_ptr()
+    L.check(L.lib().mi355q_gated_silu(C.byref(p), current_stream_ptr()))
+    if dynamic_act_scaling:
+        return q, scales
+    return q if scale is not None else out
+
+
+def swiglu(input):
+    """functional.py:736-752: x, gate = chunk(input, 2, dim=-1); silu(gate) * x."""
+    n = input.shape[-1] // 2
+    return gated_silu(input[..., n:], input[..., :n])
+
+
 def fp8_gemm(input, weights, scale_a, scale_b, dtype="float16"):
     """FP8Linear semantic (quantization/layers.py:777-879): e4m3 [M,K] x e4m3 [N,K]^T, per-tensor scales."""
     plg = Plugin("Fp8Gemm", [("type_id", str_dtype_to_trt(dtype), L.FIELD_INT32)])
