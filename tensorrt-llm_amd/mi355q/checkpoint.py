@@ -74,3 +74,63 @@ def resmooth_and_get_scale(weight_kn, pre_quant_scale, avg_pre_quant_scale, grou
         w = w * pre_quant_scale.reshape(k, 1).float() / avg_pre_quant_scale.reshape(k, 1).float()
     amax = w.T.reshape(n, k // group_size, group_size).abs().amax(-1).T.contiguous()
     return w, amax / 8.0
+
+
+# ----------------------------------------------------------------------------- SmoothQuant checkpoint tensors
+def smooth_gemm(gemm_weights, act_scales, layernorm_weights=None, layernorm_bias=None, alpha=0.5, weight_scales=None):
+    """SmoothQuant migration of a GEMM (or of several that share an input), models/llama/convert.py:148-176:
+    s[k] = clamp(act_scales[k]^alpha / max_n|W[n, k]|^(1 - alpha), 1e-5); W[:, k] *= s[k] in place, and the layer norm
+    in front of the GEMM is divided by s (weights and bias).  `gemm_weights`: [N, K] tensors ("transposed" in the
+    reference's words).  Returns s."""
+    ws = gemm_weights if isinstance(gemm_weights, (list, tuple)) else [gemm_weights]
+    k = act_scales.numel()
+    assert all(w.shape[1] == k for w in ws)
+    dtype = ws[0].dtype
+    if weight_scales is None:
+        weight_scales = torch.stack([w.abs().amax(dim=0) for w in ws]).amax(dim=0)
+    s = (act_scales.to(torch.float64).pow(alpha) / weight_scales.to(torch.float64).pow(1 - alpha)).clamp(min=1e-5)
+    if layernorm_weights is not None:
+        layernorm_weights.div_(s)
+    if layernorm_bias is not None:
+        layernorm_bias.div_(s)
+    for w in ws:
+        w.mul_(s.view(1, -1).to(w.dtype) if w.dtype != torch.float64 else s.view(1, -1))
+        assert w.dtype == dtype
+    return s
+
+
+def generate_int8(weights_kn, act_range, is_qkv=False):
+    """The SmoothQuant tensors of one linear layer from calibration ranges (models/llama/convert.py:21-126; the
+    multi-query branch is left out).  weights_kn: fp [K, N]; act_range: {"x": per-input-channel |x| max, "y":
+    per-output-channel |y| max, "w": per-output-channel |w| max [N]}.  Per-tensor (.t) and per-column (.col) variants:
+      scale_w_orig_quant = 127 / max|w|; weight.int8 = clip(round(w * scale), -127, 127);
+      scale_x_orig_quant = 127 / max|x|; scale_y_quant_orig = max|y| / 127;
+      scale_y_accum_quant = (127 / max|y|) / (scale_x_orig_quant * scale_w_orig_quant)
+    A fused QKV matrix counts as three matrices: its "per-tensor" scales are one per Q, K, V block, replicated along the
+    block's columns.  The SmoothQuantGemm plugin consumes weight.int8[.col] transposed to [N, K], scale_w_quant_orig[.col]
+    as scale_channels and (static activation scaling) scale_x_orig_quant for QuantizeTensor."""
+    import numpy as np
+    w = weights_kn.detach().cpu().double().numpy()
+    rw = act_range["w"].detach().cpu().double().numpy().reshape(-1)
+    n = w.shape[1]
+    assert rw.size == n
+    if is_qkv:
+        per_block = rw.reshape(3, -1).max(axis=1, keepdims=True)
+        w_oq_t = np.broadcast_to(127.0 / per_block, (3, n // 3)).reshape(n)
+    else:
+        w_oq_t = np.float64(127.0 / rw.max())
+    w_oq_c = 127.0 / rw
+    x_oq = 127.0 / float(act_range["x"].max())
+    y_oq = 127.0 / float(act_range["y"].max())
+    to_i8 = lambda a: np.clip(np.round(a), -127, 127).astype(np.int8)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    return {
+        "weight.int8": to_i8(w * f32(w_oq_t)),
+        "weight.int8.col": to_i8(w * f32(w_oq_c)),
+        "scale_x_orig_quant": f32(x_oq),
+        "scale_w_quant_orig": f32(1.0 / w_oq_t),
+        "scale_w_quant_orig.col": f32(1.0 / w_oq_c),
+        "scale_y_accum_quant": f32(y_oq / (x_oq * w_oq_t)),
+        "scale_y_accum_quant.col": f32(y_oq / (x_oq * w_oq_c)),
+        "scale_y_quant_orig": f32(1.0 / y_oq),
+    }

@@ -143,3 +143,47 @@ def test_awq_tensors_to_plugin_tensors():
     x = torch.randn(3, k, generator=g0)
     assert torch.allclose((x * avg) @ w2, (x * pqs) @ w_kn, rtol=1e-4, atol=1e-4)
     assert sc2.shape == (k // gs, n)
+
+
+def test_smoothquant_checkpoint_tensors():
+    """models/llama/convert.py:21-176 restated in mi355q.checkpoint: the migration leaves x @ W^T unchanged when the
+    activations are divided by the same scales, and the int8 tensors + scales reproduce the fp GEMM through the
+    oracle's SmoothQuant GEMM (a8) within the int8 quantisation error."""
+    from mi355q import checkpoint as ck
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 16, 96, 48
+    x = torch.randn(m, k, generator=g, dtype=torch.float64)
+    x[:, 7] *= 30  # an outlier channel: what SmoothQuant is for
+    w_nk = torch.randn(n, k, generator=g, dtype=torch.float64) * 0.1
+    ln = torch.ones(k, dtype=torch.float64)
+    y_ref = x @ w_nk.t()
+    w2 = w_nk.clone()
+    s = ck.smooth_gemm(w2, x.abs().amax(0), layernorm_weights=ln, alpha=0.5)
+    assert s.shape == (k,) and (s >= 1e-5).all() and s[7] == s.max()
+    assert torch.allclose((x / s) @ w2.t(), y_ref, rtol=1e-12, atol=1e-12)
+    assert torch.allclose(ln, 1.0 / s)
+    xs = x / s
+    # the migrated problem is better conditioned for int8: the outlier channel no longer dominates the range
+    assert (xs.abs().amax(0).max() / xs.abs().amax(0).median()) < (x.abs().amax(0).max() / x.abs().amax(0).median())
+
+    rng = {"x": xs.abs().amax(0), "y": y_ref.abs().amax(0), "w": w2.abs().amax(1)}
+    t = ck.generate_int8(w2.t().contiguous(), rng)
+    assert t["weight.int8"].shape == (k, n) and t["weight.int8"].dtype == np.int8
+    assert np.abs(t["weight.int8.col"]).max() == 127 and np.abs(t["weight.int8.col"]).max(axis=0).min() >= 126
+    assert t["scale_w_quant_orig.col"].shape == (n,) and t["scale_w_quant_orig"].shape == ()
+    np.testing.assert_allclose(t["scale_y_accum_quant.col"],
+                               (127.0 / rng["y"].max().item()) * t["scale_w_quant_orig.col"] / t["scale_x_orig_quant"], rtol=1e-6)
+    # static per-tensor activation scale + per-channel weights through the oracle GEMM
+    a_i8 = np.clip(np.round(xs.numpy() * t["scale_x_orig_quant"]), -128, 127).astype(np.int8)
+    out, _ = oracle.smooth_quant_gemm(torch.from_numpy(a_i8), torch.from_numpy(t["weight.int8.col"].T.copy()),
+                                   torch.tensor([1.0 / float(t["scale_x_orig_quant"])]),
+                                   torch.from_numpy(t["scale_w_quant_orig.col"]).reshape(1, n), False, True, torch.float32)
+    err = (torch.as_tensor(out).double() - y_ref).abs().max().item()
+    assert err < 0.03 * y_ref.abs().max().item(), err
+
+    # fused QKV: "per-tensor" means one scale per Q, K, V block, replicated along the block's columns
+    wq = torch.randn(k, 3 * 16, generator=g, dtype=torch.float64) * torch.tensor([1.0, 4.0, 0.25]).repeat_interleave(16)
+    tq = ck.generate_int8(wq, {"x": xs.abs().amax(0), "y": torch.ones(48), "w": wq.abs().amax(0)}, is_qkv=True)
+    sw = tq["scale_w_quant_orig"]
+    assert sw.shape == (48,) and len(set(sw[:16])) == 1 and len(set(sw[16:32])) == 1 and sw[16] > sw[0] > sw[32]
+    assert np.abs(tq["weight.int8"][:, 16:32]).max() == 127 and np.abs(tq["weight.int8"][:, 32:]).max() == 127
