@@ -63,8 +63,11 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
     const int nk = (k + (wbits == 4 ? 127 : 63)) / (wbits == 4 ? 128 : 64);
     // split K while the output tiles leave most CUs idle (fp32 slabs + reduce launch): >= 4 k-tiles per split
     int ks = 1;
+    // as many splits as still fit the chip in one residency (2 workgroups per CU): a third partial round costs more
+    // than the extra split gains (sweep in tools/lab_prefill_sweep.sh: m = 128 at 28672 x 8192, 2 splits 97 us,
+    // 3 splits 107 us incl. the reduce)
     if (wgs < 256)
-        ks = std::max(1, std::min(std::min((512 + wgs - 1) / wgs, nk / 4), 16));
+        ks = std::max(1, std::min(std::min((p.mt == 8 ? 512 : 768) / wgs, nk / 4), 16)); // 64-row tiles: 3 per CU
     const int per = (nk + ks - 1) / ks;
     p.ksplit = (nk + per - 1) / per;
     return p;
