@@ -392,8 +392,10 @@ int choose_splits(const mi355q_decode_attention_params& q, int tile)
         return std::min(env_splits, std::max(1, (q.max_seq_len + tile - 1) / tile));
     const int wgs = q.batch * q.num_kv_heads;
     const int max_tiles = (q.max_seq_len + tile - 1) / tile;
-    // aim for >= 4 workgroups per CU, never less than NW tiles per workgroup
-    int s = (1024 + wgs - 1) / wgs;
+    // aim for 2 workgroups per CU, never less than NW tiles per workgroup (a workgroup's fixed cost -- staging the new
+    // token, the cross-wave merge, its partial state -- is ~8 us: at batch 64 x 1 kv head, ctx 2048, 8 splits take
+    // 16 us, 16 splits 23 us)
+    int s = (512 + wgs - 1) / wgs;
     s = std::min(s, std::max(1, max_tiles / NW));
     return std::max(1, std::min(s, 64));
 }

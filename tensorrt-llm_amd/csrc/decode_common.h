@@ -124,10 +124,14 @@ __device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int 
                 x = T16<T>::to_float(T16<T>::from_float(x + T16<T>::to_float(bias[off])));
             smem[i] = x;
         }
-        __syncthreads();
-        if (p.pos_type == 1 || p.pos_type == 2) // kROPE_GPTJ / kROPE_GPT_NEOX
+        // cos / sin of the token's angles depend on the pair index only: one table per block (rot_dim / 2 entries)
+        // instead of powf + sincosf for every (head, pair) -- with 8 query heads per kv head that was 9x the
+        // transcendental work, in every split of the sequence
+        __shared__ float rope_tab[DH];
+        const bool rope = p.pos_type == 1 || p.pos_type == 2; // kROPE_GPTJ / kROPE_GPT_NEOX
+        const int half = p.rot_dim >> 1;
+        if (rope && tid < half)
         {
-            const int half = p.rot_dim >> 1;
             float base = p.rot_base, scale = p.rot_scale;
             // update_rotary_base_n_scale (decoderMaskedMultiheadAttentionUtils.h:2552-2579)
             if (p.rot_scale_type == 2)
@@ -141,15 +145,22 @@ __device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int 
             }
             else if (p.rot_scale_type == 1)
                 scale = 1.f / scale;
+            const float ang = ((float) tl * scale) / powf(base, (float) (2 * tid) / (float) p.rot_dim);
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            rope_tab[2 * tid] = cs;
+            rope_tab[2 * tid + 1] = sn;
+        }
+        __syncthreads();
+        if (rope)
+        {
             for (int i = tid; i < (G + 1) * half; i += NW * 64)
             {
                 int vec = i / half, j = i % half;
                 float* x = smem + vec * DH;
                 int i0 = p.pos_type == 2 ? j : 2 * j;
                 int i1 = p.pos_type == 2 ? j + half : 2 * j + 1;
-                float ang = ((float) tl * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
-                float sn, cs;
-                sincosf(ang, &sn, &cs);
+                const float cs = rope_tab[2 * j], sn = rope_tab[2 * j + 1];
                 float a = x[i0], c = x[i1];
                 x[i0] = T16<T>::to_float(T16<T>::from_float(cs * a - sn * c));
                 x[i1] = T16<T>::to_float(T16<T>::from_float(cs * c + sn * a));
