@@ -93,9 +93,10 @@ def test_gated_silu_edges(cuda):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("rows,cols", [(5, 64), (4096, 5120), (64, 13824), (9, 28672)])
+@pytest.mark.parametrize("rows,cols", [(5, 64), (4096, 5120), (64, 13824), (9, 28672), (37, 1001), (3, 40000)])
 def test_per_token_quantization_one_pass(cuda, dtype, rows, cols):
-    # the row kernel now serves quantize_per_token whenever cols % 8 == 0: bit-exact with the oracle (a10)
+    # the row kernel serves quantize_per_token whenever cols % 8 == 0 and cols <= 32768 (the last two shapes take the
+    # two-pass kernel): bit-exact with the oracle either way (a10)
     g = torch.Generator().manual_seed(rows + cols)
     x = (torch.randn(rows, cols, generator=g) * 3).to(dtype)
     q, s = F.quantize_per_token(x.to(cuda))
