@@ -180,7 +180,11 @@ __device__ __forceinline__ bool gemv_ring_round(F& step, std::integer_sequence<i
 // MC = 16-row chunks of m handled by one block (1, 2): for 16 < m <= 32 the weights are still streamed ONCE and
 // every unpacked fragment feeds MC MFMAs (the prefill GEMM's 2-barrier tile loop is latency-bound at these sizes).
 // NBUF = register images in the ring (NBUF - 1 chunks of CH tiles in flight during a chunk's compute).
-template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ, int MC, int NBUF>
+// WPN ("wave per n-block"): instead of splitting the block's k segment over the waves, wave w takes n-block 16 s + w
+// of the block's current set s over the WHOLE segment -- no cross-wave reduction, no barrier after the staging, the
+// accumulators go straight to the output (or the split-K slab).  For 16 < m <= 32, where the activation slab forces
+// short k segments and the per-n-block reduction (two barriers for one tile per wave) was most of the time.
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int NSZ, int MC, int NBUF, bool WPN = false>
 __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 {
     constexpr int KTILE = Geo<WBITS>::KTILE;
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     const int m0 = blockIdx.y * 16 * MC;
     const int kh = (lane >> 4) * 8;
     const int rows = min(16 * MC, a.m - m0);
-    const int nblocks = a.n >> 4;
+    const int nblocks_all = a.n >> 4;
+    const int nblocks = WPN ? (nblocks_all + NWAVES - 1) / NWAVES : nblocks_all; // WPN: sets of NWAVES n-blocks
     const int nb_stride = gridDim.x;
     // Workgroups go to the 8 XCDs round-robin, so blocks with equal blockIdx.x % 8 share an L2.  Give each XCD a
     // contiguous range of n-blocks per round: a 128-byte line of scales / zeros covers 4 n-blocks, and with
@@ -214,9 +219,9 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     const int seg = (a.ktiles + a.ksplit - 1) / a.ksplit; // 0 when k == 64 on int4: half tile only
     const int seg_begin = blockIdx.z * seg;
     const int seg_end = min(a.ktiles, seg_begin + seg);
-    const int tpw = (seg + NWAVES - 1) / NWAVES; // tiles per wave (block-uniform)
+    const int tpw = WPN ? seg : (seg + NWAVES - 1) / NWAVES; // tiles per wave (block-uniform)
     const int cpw = max(1, (tpw + CH - 1) / CH);   // chunks per wave per n-block (block-uniform)
-    const int kt_begin = seg_begin + wave * tpw;
+    const int kt_begin = WPN ? seg_begin : seg_begin + wave * tpw;
     const int kt_end = min(seg_end, kt_begin + tpw); // may be <= kt_begin: this wave only helps reduce
     const int kt_hi = max(seg_end - 1, 0);           // clamp for dead tiles (a valid tile of the segment)
     const bool half_tile = WBITS == 4 && (a.k & 127) && blockIdx.z == a.ksplit - 1;
@@ -239,6 +244,12 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     // that was requested a moment ago (no prefetch at all).
     auto issue = [&](GemvChunk<CH, NSZ>& c, int nb, int ck, bool live)
     {
+        if constexpr (WPN)
+        {
+            nb = nb * NWAVES + wave;
+            live = live && nb < nblocks_all;
+            nb = live ? nb : 0;
+        }
         src.w = make_rsrc(a.qweight + (size_t) nb * run_bytes, live ? run_bytes : 0);
         src.s = live ? s_rsrc : s_dead;
         src.z = live ? z_rsrc : z_dead;
@@ -364,7 +375,11 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
     int it = 0; // n-blocks this block has finished (the same sequence in every wave)
     auto flush = [&](int nb)
     {
-        if (half_tile && wave == 0)
+        if constexpr (WPN)
+            nb = nb * NWAVES + wave;
+        if (WPN && nb >= nblocks_all)
+            return;
+        if (half_tile && (WPN || wave == 0))
         {
             // int4 with K % 128 == 64: the run ends with a 512-byte half tile (2 k-steps)
             const int col = nb * 16 + (lane & 15);
@@ -378,6 +393,31 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
                 gemv_tile_int4<T, 1, 2, MC>(
                     w, acc, &s, &z, [&](int mc, int st) { return afrag(mc, a.ktiles, st); },
                     [&](int mc, int) { return s1frag(mc, a.ktiles, 0); });
+        }
+        if constexpr (WPN)
+        {
+            // this wave owns the n-block: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+            const int on = lane & 15;
+            const float bias = (a.ksplit == 1 && a.bias) ? T16<T>::to_float(a.bias[nb * 16 + on]) : 0.f;
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc)
+            {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                {
+                    const int om = 16 * mc + (lane >> 4) * 4 + r;
+                    if (om < rows)
+                    {
+                        const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
+                        if (a.ksplit == 1)
+                            a.out[oi] = T16<T>::from_float(acc[mc][r] + bias);
+                        else
+                            a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = acc[mc][r];
+                    }
+                }
+                acc[mc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
         }
         // RB == 2: this n-block's buffer was last read two n-blocks ago, and every reader has passed the barrier of the
         // n-block in between -- one barrier per n-block.  (Tried: no barrier at all -- every wave counts itself into
@@ -574,12 +614,13 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
 struct GemvPlan
 {
     int ksplit, nwaves, ngroups, mc, red_buffers;
+    bool wpn; // wave-per-n-block mode (see woq_gemv_kernel)
     size_t lds_bytes;
 };
 
-// Two 16-row chunks per block at most: the block's activation slab [rows][k segment] must fit LDS beside the reduce
-// buffer, and at 64 rows the k segments become so short (K/16) that most of a block's 16 waves idle (measured
-// 37 us vs 23 us for the prefill GEMM at 64 x 3584 x 8192; 32 rows: 17 us vs 19 us).  Larger m: prefill GEMM.
+// Two 16-row chunks per block at most (wave-per-n-block mode, see the kernel): the block's activation slab
+// [rows][k segment] must fit LDS, and with four chunks the k segments get so short that the fp32 split-K slabs and
+// their reduce cost more than the prefill GEMM (m = 64 at 28672 x 8192: 51 + 13 us against 54 + 7 us).
 constexpr int GEMV_MAX_M = 32;
 
 int gemv_mc(int m)
@@ -609,6 +650,28 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     p.nwaves = 16; // one 16-wave block per CU: all of a CU's waves finish an n-block together
     // k segments: (a) the activation slab of a segment must fit LDS, (b) when the n-blocks alone leave
     // most CUs idle, split K across blocks (fp32 slabs + a reduce launch, so only if really idle)
+    static const int lab_wpn = getenv("MI355Q_GEMV_WPN") ? atoi(getenv("MI355Q_GEMV_WPN")) : -1; // lab: 0 / 1 force
+    const int sets = (nblocks + p.nwaves - 1) / p.nwaves;
+    // wave-per-n-block mode: two 16-row chunks (whose slab forces short k segments anyway) and enough sets of 16
+    // n-blocks to give every CU a few
+    p.wpn = lab_wpn >= 0 ? ((lab_wpn == 1 && p.mc >= 2) || lab_wpn == 2) : p.mc >= 2;
+    if (p.wpn)
+    {
+        p.red_buffers = 0;
+        int ks = 1;
+        while (ks < ktiles && gemv_lds_bytes(m, k, ktile, ktiles, ks, p.nwaves, 0) > GEMV_LDS_MAX)
+            ++ks;
+        while (sets * mchunks * ks < GEMV_CUS && ktiles / (ks + 1) >= 4)
+            ++ks;
+        const int seg = std::max(1, (ktiles + ks - 1) / ks);
+        p.ksplit = std::max(1, (ktiles + seg - 1) / seg);
+        const int slots = std::max(1, GEMV_CUS / (mchunks * p.ksplit));
+        const int iters = (sets + slots - 1) / slots;
+        p.ngroups = (sets + iters - 1) / iters;
+        p.lds_bytes = gemv_lds_bytes(m, k, ktile, ktiles, p.ksplit, p.nwaves, 0);
+        MQ_CHECK(p.lds_bytes <= GEMV_LDS_MAX, "k=%d too large for the decode kernel's LDS activation slab", k);
+        return p;
+    }
     // two reduce buffers (one barrier per n-block) unless a single one saves a k split, i.e. the fp32 slabs and the
     // reduce launch (m = 16 at k = 4096: 128 KiB of rows + 32 KiB of buffers do not fit, + 16 KiB do)
     auto min_split = [&](int rb)
@@ -638,13 +701,13 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     return p;
 }
 
-template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int MC, int NBUF>
+template <typename T, int WBITS, bool ZERO, int NWAVES, int CH, int MC, int NBUF, bool WPN = false>
 void launch_gemv_variant(const WoqArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     // two (scale, zero) pairs per tile only when a 128-row int4 tile spans two groups of 64
     const bool split = WBITS == 4 && a.group == 64;
-    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1), MC, NBUF>
-                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1, MC, NBUF>;
+    auto kern = split ? woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, (WBITS == 4 ? 2 : 1), MC, NBUF, WPN>
+                      : woq_gemv_kernel<T, WBITS, ZERO, NWAVES, CH, 1, MC, NBUF, WPN>;
     if (lds_bytes > 64 * 1024)
     {
         MQ_HIP(hipFuncSetAttribute(
@@ -663,6 +726,8 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
     {
         q.ksplit = 1;
         q.red_buffers = 1;
+        q.wpn = false;
+        q.ngroups = std::min(p.wpn ? GEMV_CUS : p.ngroups, a.n / 16);
         q.lds_bytes = gemv_lds_bytes(a.m, a.k, Geo<WBITS>::KTILE, a.ktiles, 1, p.nwaves, 1);
         MQ_CHECK(q.lds_bytes <= GEMV_LDS_MAX,
             "this m/k needs the split-K workspace (mi355q_weight_only_gemm_workspace_size)");
@@ -673,7 +738,11 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
     // ring geometry: 3 register images of 2 tiles (measured best of {2x4, 3x4, 4x2, 6x2, 3x2, 4x1, 6x1, 8x1} at
     // 28672 x 8192 and no worse elsewhere); MI355Q_GEMV_RING = 10 * images + tiles selects the lab alternatives
     static const int lab = getenv("MI355Q_GEMV_RING") ? atoi(getenv("MI355Q_GEMV_RING")) : 0;
-    if (q.mc == 2 && lab == 32)
+    if (q.wpn && q.mc == 2)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 3, true>(ka, grid, q.lds_bytes, stream);
+    else if (q.wpn)
+        launch_gemv_variant<T, WBITS, ZERO, 16, 2, 1, 3, true>(ka, grid, q.lds_bytes, stream);
+    else if (q.mc == 2 && lab == 32)
         launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 3>(ka, grid, q.lds_bytes, stream);
     else if (q.mc == 2)
         launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 2>(ka, grid, q.lds_bytes, stream);
@@ -726,7 +795,7 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
     size_t best = 0;
     for (int mm = 1; mm <= m; mm = (mm < 64 || m - mm < 16) ? mm + 1 : mm + 16) // every m' up to 64, then 16s, then m
     {
-        const int s = (mm > GEMV_MAX_M && woq_prefill_supported(mm, n, k)) ? woq_prefill_ksplit(mm, n, k, weight_type)
+        const int s = !woq_gemm_fuses_act_scale(mm, n, k) ? woq_prefill_ksplit(mm, n, k, weight_type)
                                                                              : woq_choose_ksplit(mm, n, k, weight_type);
         if (s > 1)
             best = std::max(best, (size_t) s * mm * n * sizeof(float));
