@@ -109,12 +109,13 @@ def bench_decode_attention(dev, steps, B=64, Hq=8, Hkv=1, D=128, ctx=2048, tpb=6
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
+            per_graph = sets * max(1, -(-8 // sets))  # >= 8 enqueues per graph: a graph launch costs ~25 us itself
             with torch.cuda.graph(graph, stream=side):
-                for _ in range(sets):
+                for _ in range(per_graph):
                     step()
-        reps = max(1, steps // sets)
+        reps = max(1, steps // per_graph)
         _, dev_s = time_steps(graph.replay, reps, 2, lambda: None)
-        steps = reps * sets
+        steps = reps * per_graph
         launches = "hipGraph"
     except Exception:
         torch.cuda.synchronize()
@@ -466,7 +467,8 @@ def main():
                                      bench_gemv(dev, 2 * 72, m=1, n=11008, k=4096, sets=24),
                                      bench_gemv(dev, 2 * 72, m=1, n=4096, k=11008, sets=24),
                                      bench_gemv(dev, 48, m=1, n=28672, k=8192, sets=6),
-                                     bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6)]
+                                     bench_gemv(dev, 48, m=16, n=28672, k=8192, sets=6),
+                                     bench_gemv(dev, 48, m=32, n=28672, k=8192, sets=6)]
                 sec["decode_attention_other"] = [
                     bench_decode_attention(dev, 48, Hq=32, Hkv=32, kv="bf16", ragged=True),          # cfg2 ragged
                     bench_decode_attention(dev, 96, Hq=8, Hkv=1, kv="int8", sets=12),                 # cfg4 per-GPU slice
