@@ -459,7 +459,7 @@ def main():
                 tj = json.load(f)
             res["roofline"]["traffic"] = tj.get("decode_attn_kernel_bytes_per_launch")
             res["roofline"]["traffic_source"] = tj.get("source")
-        if not args.no_secondary:
+        if not args.no_secondary and world == 1:  # side measurements and the CPU baseline: N = 1 only
             sec = {}
             try:
                 sec["w4a16_gemv"] = [bench_gemv(dev, 4 * 72, m=1), bench_gemv(dev, 4 * 72, m=1, pre_quant=True),
@@ -489,7 +489,7 @@ def main():
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)
             res["secondary"] = sec
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_attention(H, D, ctx, tpb)
         print(json.dumps(res))
     if world > 1:
