@@ -527,6 +527,8 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
 {
     Plan pl = make_plan(q);
     MQ_CHECK(q.qkv && q.out && q.sequence_lengths && q.block_pointers, "null tensor");
+    MQ_CHECK(((uintptr_t) q.qkv & 15) == 0 && ((uintptr_t) q.qkv_bias & 15) == 0,
+        "qkv / qkv_bias must be 16-byte aligned (the new token is staged with 16-byte loads)");
     if (pl.kvb == 1)
         MQ_CHECK(q.kv_scale_orig_quant && q.kv_scale_quant_orig, "8-bit kv cache needs both scales");
     DecodeArgs a{};

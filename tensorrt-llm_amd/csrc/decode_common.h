@@ -115,14 +115,47 @@ __device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int 
     {
         const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * DH;
         const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.qkv_bias);
-        for (int i = tid; i < (G + 2) * DH; i += NW * 64)
+        // 16-byte loads, all of them issued before the first use: the scalar form (one 2-byte load per trip of a
+        // 5-trip loop, each waited for) cost five cold HBM round trips -- most of a workgroup's fixed ~8 us
+        constexpr int NV = (G + 2) * DH / 8;                     // 16-byte vectors of q (G heads), k, v
+        constexpr int TRIPS = (NV + NW * 64 - 1) / (NW * 64);
+        uint4 xv[TRIPS], bv[TRIPS];
+        int offv[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t)
         {
-            int vec = i / DH, d = i % DH;
-            int off = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
-            float x = T16<T>::to_float(qkv[off]);
-            if (bias)
-                x = T16<T>::to_float(T16<T>::from_float(x + T16<T>::to_float(bias[off])));
-            smem[i] = x;
+            const int v = min(tid + t * NW * 64, NV - 1); // past the end: a valid vector, not stored
+            const int vec = (v * 8) / DH, d = (v * 8) % DH;
+            offv[t] = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
+            xv[t] = *reinterpret_cast<const uint4*>(qkv + offv[t]);
+            bv[t] = make_uint4(0, 0, 0, 0);
+        }
+        if (bias)
+        {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t)
+                bv[t] = *reinterpret_cast<const uint4*>(bias + offv[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t)
+        {
+            const int v = tid + t * NW * 64;
+            if (v < NV)
+            {
+                const uint32_t xw[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w};
+                const uint32_t bw[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                {
+                    float x = (j & 1) ? T16<T>::hi(xw[j >> 1]) : T16<T>::lo(xw[j >> 1]);
+                    if (bias)
+                    {
+                        const float bb = (j & 1) ? T16<T>::hi(bw[j >> 1]) : T16<T>::lo(bw[j >> 1]);
+                        x = T16<T>::to_float(T16<T>::from_float(x + bb));
+                    }
+                    smem[v * 8 + j] = x;
+                }
+            }
         }
         // cos / sin of the token's angles depend on the pair index only: one table per block (rot_dim / 2 entries)
         // instead of powf + sincosf for every (head, pair) -- with 8 query heads per kv head that was 9x the
