@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -64,6 +65,18 @@ mi355q_status guarded(F&& f) noexcept
         set_last_error(e.what());
         return MI355Q_ERR_INTERNAL;
     }
+}
+
+// Lab switches (measured alternatives) exist only in a `make LAB=1` build: the release library
+// reads no environment variable on any call path.
+inline const char* lab_env(const char* name)
+{
+#ifdef MI355Q_LAB
+    return std::getenv(name);
+#else
+    (void) name;
+    return nullptr;
+#endif
 }
 
 inline size_t dtype_size(int t)

@@ -385,13 +385,15 @@ int ilog2(int x)
 
 int choose_splits(const mi355q_decode_attention_params& q, int tile)
 {
+    // every path ends at min(64, tiles): the merge holds 64 rescale factors, and a split without a tile is wasted
+    const int max_tiles = std::max(1, (q.max_seq_len + tile - 1) / tile);
+    const int cap = std::min(64, max_tiles);
     if (q.multi_block_mode > 0)
-        return std::min(q.multi_block_mode, 64); // the merge kernel handles up to 64 partials
-    static const int env_splits = getenv("MI355Q_ATTN_SPLITS") ? atoi(getenv("MI355Q_ATTN_SPLITS")) : 0; // lab
+        return std::min(q.multi_block_mode, cap);
+    static const int env_splits = lab_env("MI355Q_ATTN_SPLITS") ? atoi(lab_env("MI355Q_ATTN_SPLITS")) : 0; // lab
     if (env_splits > 0)
-        return std::min(env_splits, std::max(1, (q.max_seq_len + tile - 1) / tile));
+        return std::min(env_splits, cap);
     const int wgs = q.batch * q.num_kv_heads;
-    const int max_tiles = (q.max_seq_len + tile - 1) / tile;
     // aim for 2 workgroups per CU, never less than NW tiles per workgroup (a workgroup's fixed cost -- staging the new
     // token, the cross-wave merge, its partial state -- is ~8 us: at batch 64 x 1 kv head, ctx 2048, 8 splits take
     // 16 us, 16 splits 23 us)

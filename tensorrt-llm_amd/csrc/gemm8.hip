@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
 template <bool FP8>
 void launch_phased(const Gemm8Args& g, hipStream_t stream)
 {
-    static const int group_m = getenv("MI355Q_GEMM8_GROUP_M") ? std::max(1, atoi(getenv("MI355Q_GEMM8_GROUP_M"))) : 4;
+    static const int group_m = lab_env("MI355Q_GEMM8_GROUP_M") ? std::max(1, atoi(lab_env("MI355Q_GEMM8_GROUP_M"))) : 4;
     hipLaunchKernelGGL(gemm8_phased_kernel<FP8>, dim3((g.m / 256) * (g.n / 256)), dim3(512), 0, stream, g, g.m / 256,
         g.n / 256, group_m);
 }
@@ -707,7 +707,7 @@ bool try_launch_big_int8(const Gemm8Args& g, hipStream_t stream)
 {
     if (g.k % 128 != 0 || g.m % 128 != 0 || g.n % 128 != 0)
         return false;
-    const char* force = getenv("MI355Q_GEMM8_TILE"); // measurement override: 0..2 single shape, 3 = old 256^2 kernel
+    const char* force = lab_env("MI355Q_GEMM8_TILE"); // measurement override: 0..2 single shape, 3 = old 256^2 kernel
     if (force && force[0] >= '0' && force[0] <= '2' && tile_cost(TILES[force[0] - '0'], g.m, g.n) < 1e29)
     {
         launch_tile(force[0] - '0', g, stream);
@@ -937,7 +937,7 @@ void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* sc
     // per-tensor scales: alpha_row = scaleA[0], alpha_col = scaleB[0]
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, scaleB, scaleA, 0, 0, m,
         n, k, out_type, n};
-    if (m % 256 == 0 && n % 256 == 0 && k % 128 == 0 && !getenv("MI355Q_FP8_SMALL_TILE"))
+    if (m % 256 == 0 && n % 256 == 0 && k % 128 == 0 && !lab_env("MI355Q_FP8_SMALL_TILE"))
         launch_phased<true>(g, stream);
     else
     {
@@ -953,7 +953,7 @@ void per_token_quantization(
     MQ_CHECK(dst && src && scales, "null tensor");
     if (rows == 0)
         return;
-    static const bool lab_scalar = getenv("MI355Q_PTQ_SCALAR") != nullptr; // lab: the two-pass scalar kernel below
+    static const bool lab_scalar = lab_env("MI355Q_PTQ_SCALAR") != nullptr; // lab: the two-pass scalar kernel below
     if (row_quant_supported(cols) && !lab_scalar
         && (src_type == MI355Q_FLOAT || src_type == MI355Q_HALF || src_type == MI355Q_BF16))
     {

@@ -20,6 +20,19 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
 bool woq_gemm_fuses_act_scale(int m, int n, int k); // then weight_only_gemm accepts p.act_scale (no separate smoothing pass)
 void weight_only_dequantize(const mi355q_weight_only_params& p, hipStream_t stream);
 
+// woq_gemv_small.hip: the light decode GEMV (m <= 16, one launch, in-launch split-K)
+struct LightPlan
+{
+    bool applies;
+    int ksplit, seg_tiles; // k segments per n-block, k-tiles per segment
+    size_t workspace_bytes; // partial tiles + arrival words (split-K only)
+};
+// above these the persistent kernel of woq_gemm.hip (16-wave workgroups that stay resident, LDS activation slab) wins
+constexpr size_t LIGHT_MAX_WEIGHT_BYTES = 160u << 20, LIGHT_MAX_WEIGHT_BYTES_16ROWS = 24u << 20;
+LightPlan woq_light_plan(int m, int n, int k, int weight_type);
+void weight_only_gemv_light(const mi355q_weight_only_params& p, LightPlan pl, void* workspace, size_t workspace_bytes,
+    hipStream_t stream);
+
 // woq_prefill.hip
 struct WoqArgsHost
 {

@@ -520,7 +520,7 @@ void launch_norm(const NormArgs& a, hipStream_t stream)
     // 16384 x 4096 fp16, dynamic scale: 64 threads 49.0 us, 128 threads 43.8 us, 256 threads 46.6 us -- the row
     // width hardly matters, and neither did halving the VALU work of the quantisation (a plain torch copy of the same
     // footprint reaches 5.8 TB/s, this kernel 4.6)
-    static const int lab_nt = getenv("MI355Q_NORM_NT") ? atoi(getenv("MI355Q_NORM_NT")) : 0;
+    static const int lab_nt = lab_env("MI355Q_NORM_NT") ? atoi(lab_env("MI355Q_NORM_NT")) : 0;
     const int nt = lab_nt ? lab_nt : (a.hidden <= 8192 ? 128 : 256);
     const int vpt = (a.hidden + nt * 8 - 1) / (nt * 8);
     if (a.hidden % 8 != 0 || a.hidden > 16384 || vpt > 8)

@@ -159,6 +159,7 @@ struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
     GemmDims mDims;
     int mPreQuantScaleInputIdx, mWeightInputIdx, mScalesInputIdx, mZerosInputIdx, mBiasesInputIdx, mAlphaInputIdx;
     size_t m_workspaceMaxSize = 0;
+    int m_cfgMaxM = -1, m_cfgN = -1, m_cfgK = -1; // maxima of the last configurePlugin (what the workspace was sized for)
 
     WeightOnlyGroupwiseQuantMatmulPlugin(int type, int quant_algo, int group_size)
     {
@@ -217,6 +218,7 @@ struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
         if (!mDims.isInitialized())
             mDims = {minM, maxM, maxN / FP16_INT4_RATIO, maxK};
         m_workspaceMaxSize = mi355q_weight_only_gemm_workspace_size(maxM, maxN, maxK, MI355Q_WEIGHT_INT4);
+        m_cfgMaxM = maxM, m_cfgN = maxN, m_cfgK = maxK;
     }
     size_t workspaceSize(const mi355q_tensor_desc*, int, const mi355q_tensor_desc*, int) const override
     {
@@ -243,9 +245,12 @@ struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
         p.weight_type = MI355Q_WEIGHT_INT4;
         p.act_type = mType;
         p.workspace = workspace;
-        p.workspace_bytes = workspace ? mi355q_weight_only_gemm_workspace_size(m, p.n, k, MI355Q_WEIGHT_INT4) : 0;
-        if (m_workspaceMaxSize)
-            p.workspace_bytes = std::max(p.workspace_bytes, workspace ? m_workspaceMaxSize : 0);
+        // only what getWorkspaceSize promised (the size configurePlugin computed for maxM); without a configure call
+        // nothing is claimed and the kernels run their workspace-free form (ksplit = 1)
+        if (m_cfgMaxM >= 0)
+            MQ_CHECK(m <= m_cfgMaxM && p.n <= m_cfgN && k <= m_cfgK,
+                "enqueue shape m=%d n=%d k=%d outside the configured maxima m=%d n=%d k=%d", m, p.n, k, m_cfgMaxM, m_cfgN, m_cfgK);
+        p.workspace_bytes = workspace ? m_workspaceMaxSize : 0;
         weight_only_gemm_entry(p, stream);
     }
     size_t serializationSize() const override // :552-559 (minus the profiler's tactic table)
@@ -268,6 +273,7 @@ struct WeightOnlyQuantMatmulPlugin : PluginBase
     int32_t mType, mWeightTypeId;
     GemmDims mDims;
     size_t m_workspaceMaxSize = 0;
+    int m_cfgMaxM = -1, m_cfgN = -1, m_cfgK = -1; // maxima of the last configurePlugin (what the workspace was sized for)
     WeightOnlyQuantMatmulPlugin(int type, int weightTypeId)
         : mType(type)
         , mWeightTypeId(weightTypeId)
@@ -320,6 +326,7 @@ struct WeightOnlyQuantMatmulPlugin : PluginBase
         if (!mDims.isInitialized())
             mDims = {minM, maxM, maxN / ratio(), maxK};
         m_workspaceMaxSize = mi355q_weight_only_gemm_workspace_size(maxM, maxN, maxK, mWeightTypeId);
+        m_cfgMaxM = maxM, m_cfgN = maxN, m_cfgK = maxK;
     }
     size_t workspaceSize(const mi355q_tensor_desc*, int, const mi355q_tensor_desc*, int) const override
     {
@@ -340,9 +347,10 @@ struct WeightOnlyQuantMatmulPlugin : PluginBase
         p.weight_type = mWeightTypeId;
         p.act_type = mType;
         p.workspace = workspace;
-        p.workspace_bytes = workspace ? std::max(m_workspaceMaxSize,
-                                mi355q_weight_only_gemm_workspace_size(p.m, p.n, p.k, mWeightTypeId))
-                                      : 0;
+        if (m_cfgMaxM >= 0)
+            MQ_CHECK(p.m <= m_cfgMaxM && p.n <= m_cfgN && p.k <= m_cfgK,
+                "enqueue shape m=%d n=%d k=%d outside the configured maxima m=%d n=%d k=%d", p.m, p.n, p.k, m_cfgMaxM, m_cfgN, m_cfgK);
+        p.workspace_bytes = workspace ? m_workspaceMaxSize : 0; // what getWorkspaceSize promised, nothing more
         weight_only_gemm_entry(p, stream);
     }
     size_t serializationSize() const override // :384-399
@@ -1525,7 +1533,7 @@ extern "C"
     const char* const* mi355q_get_plugin_names(int32_t* nbPlugins)
     {
         if (nbPlugins)
-            *nbPlugins = 6;
+            *nbPlugins = (int32_t) (sizeof(kPluginNames) / sizeof(kPluginNames[0])) - 1; // the nullptr terminator
         return kPluginNames;
     }
 

@@ -650,7 +650,7 @@ GemvPlan plan_gemv(int m, int n, int k, int wbits)
     p.nwaves = 16; // one 16-wave block per CU: all of a CU's waves finish an n-block together
     // k segments: (a) the activation slab of a segment must fit LDS, (b) when the n-blocks alone leave
     // most CUs idle, split K across blocks (fp32 slabs + a reduce launch, so only if really idle)
-    static const int lab_wpn = getenv("MI355Q_GEMV_WPN") ? atoi(getenv("MI355Q_GEMV_WPN")) : -1; // lab: 0 / 1 force
+    static const int lab_wpn = lab_env("MI355Q_GEMV_WPN") ? atoi(lab_env("MI355Q_GEMV_WPN")) : -1; // lab: 0 / 1 force
     const int sets = (nblocks + p.nwaves - 1) / p.nwaves;
     // wave-per-n-block mode: two 16-row chunks (whose slab forces short k segments anyway) and enough sets of 16
     // n-blocks to give every CU a few
@@ -737,7 +737,7 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
     dim3 grid(q.ngroups, (a.m + 16 * q.mc - 1) / (16 * q.mc), q.ksplit);
     // ring geometry: 3 register images of 2 tiles (measured best of {2x4, 3x4, 4x2, 6x2, 3x2, 4x1, 6x1, 8x1} at
     // 28672 x 8192 and no worse elsewhere); MI355Q_GEMV_RING = 10 * images + tiles selects the lab alternatives
-    static const int lab = getenv("MI355Q_GEMV_RING") ? atoi(getenv("MI355Q_GEMV_RING")) : 0;
+    static const int lab = lab_env("MI355Q_GEMV_RING") ? atoi(lab_env("MI355Q_GEMV_RING")) : 0;
     if (q.wpn && q.mc == 2)
         launch_gemv_variant<T, WBITS, ZERO, 16, 2, 2, 3, true>(ka, grid, q.lds_bytes, stream);
     else if (q.wpn)
@@ -795,6 +795,15 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
     size_t best = 0;
     for (int mm = 1; mm <= m; mm = (mm < 64 || m - mm < 16) ? mm + 1 : mm + 16) // every m' up to 64, then 16s, then m
     {
+        if (woq_gemm_fuses_act_scale(mm, n, k))
+        {
+            const LightPlan lp = woq_light_plan(mm, n, k, weight_type);
+            if (lp.applies)
+            {
+                best = std::max(best, lp.workspace_bytes);
+                continue;
+            }
+        }
         const int s = !woq_gemm_fuses_act_scale(mm, n, k) ? woq_prefill_ksplit(mm, n, k, weight_type)
                                                                              : woq_choose_ksplit(mm, n, k, weight_type);
         if (s > 1)
@@ -818,8 +827,8 @@ void woq_splitk_reduce(const float* slabs, const void* bias, void* out, int m, i
 // m <= 32 (or shapes the prefill GEMM does not take) run the decode kernel, which applies the pre-quant scale itself
 bool woq_gemm_fuses_act_scale(int m, int n, int k)
 {
-    static const int gemv_max_m = std::getenv("MI355Q_GEMV_MAX_M") ? atoi(std::getenv("MI355Q_GEMV_MAX_M")) : GEMV_MAX_M;
-    return !(m > gemv_max_m && woq_prefill_supported(m, n, k) && !std::getenv("MI355Q_NO_PREFILL"));
+    static const int gemv_max_m = lab_env("MI355Q_GEMV_MAX_M") ? atoi(lab_env("MI355Q_GEMV_MAX_M")) : GEMV_MAX_M;
+    return !(m > gemv_max_m && woq_prefill_supported(m, n, k) && !lab_env("MI355Q_NO_PREFILL"));
 }
 
 void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream)
@@ -843,6 +852,15 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
             woq_splitk_reduce(slabs, p.bias, p.out, p.m, p.n, ks, p.act_type == MI355Q_BF16, stream);
         MQ_HIP(hipGetLastError());
         return;
+    }
+    {
+        // m <= 16 at decode-sized weights: the light kernel (woq_gemv_small.hip), one launch whatever the k split
+        const LightPlan lp = woq_light_plan(p.m, p.n, p.k, p.weight_type);
+        if (lp.applies)
+        {
+            weight_only_gemv_light(p, lp, workspace, workspace_bytes, stream);
+            return;
+        }
     }
     a.act_scale = static_cast<const uint16_t*>(p.act_scale); // decode kernel: applied while the rows are staged
     a.ksplit = woq_choose_ksplit(p.m, p.n, p.k, p.weight_type);
