@@ -296,6 +296,15 @@ extern "C"
     } mi355q_decode_attention_params;
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
     mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);
+    /* No counterpart in the reference.  The same generation step for callers that cannot allocate and have no
+     * workspace to hand over (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc):
+     * params->workspace / workspace_bytes are ignored; the split-KV partials go to a static device array inside the
+     * library (mi355q_decode_attention_static_scratch_size() bytes per GPU, held until the process ends).  Calls no
+     * hipMalloc / hipFree; a call whose partials would not fit returns MI355Q_ERR_INVALID_ARGUMENT.  All calls on
+     * one GPU share that array: calls that overlap on one GPU (two streams) race -- serialise them.  The first call
+     * on each device resolves the array's address (hipGetSymbolAddress); make it outside a graph capture. */
+    size_t mi355q_decode_attention_static_scratch_size(void);
+    mi355q_status mi355q_masked_multihead_attention_static(const mi355q_decode_attention_params* params, void* stream);
 
     /* The context (prefill) phase of GPTAttention: plugins/gptAttentionCommon/gptAttentionCommon.cpp:641-1133
      * enqueueContext = invokeAddFusedQKVBiasTranspose / invokeApplyBiasRopeUpdateKVCache

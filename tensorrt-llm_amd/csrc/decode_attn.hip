@@ -15,7 +15,9 @@
 //     keeps partials in fp32).
 //   * the new token's bias + RoPE + cache append (quantised for int8/fp8 caches) is fused in.
 #include "decode_common.h"
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 namespace mi355q
 {
@@ -579,6 +581,66 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
     else
         dispatch_kv<f16_t>(q, a, pl.u, stream);
     MQ_HIP(hipGetLastError());
+}
+
+// ---- the entry point that allocates nothing and takes no workspace (mi355q_masked_multihead_attention_static).
+// The split-KV partials live in a file-scope device array of the code object: every GPU the library runs on holds its
+// own copy at its own address until the process ends.  In host code the array's NAME is only a stand-in for the symbol
+// (passing it to a kernel compiles and then faults on the GPU): its device address is resolved once per device with
+// hipGetSymbolAddress and only that pointer is used afterwards.
+namespace
+{
+constexpr size_t DECODE_SCRATCH_BYTES = size_t(8) << 20;
+static __device__ __align__(256) unsigned char scratch[DECODE_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+std::atomic<void*> g_scratch_ptr[MAX_DEVICES];
+std::mutex g_scratch_mutex;
+
+void* decode_scratch_of_current_device()
+{
+    int dev = -1;
+    MQ_HIP(hipGetDevice(&dev));
+    MQ_CHECK(dev >= 0 && dev < MAX_DEVICES, "device ordinal %d outside 0..%d", dev, MAX_DEVICES - 1);
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p)
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (!p)
+        {
+            MQ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))); // this device's copy (the device is current)
+            MQ_CHECK(p != nullptr, "hipGetSymbolAddress returned a null address");
+            g_scratch_ptr[dev].store(p, std::memory_order_release);
+        }
+    }
+    return p;
+}
+} // namespace
+
+size_t decode_attention_static_scratch_bytes()
+{
+    return DECODE_SCRATCH_BYTES;
+}
+
+void masked_multihead_attention_static(const mi355q_decode_attention_params& q, hipStream_t stream)
+{
+    const Plan pl = make_plan(q);
+    mi355q_decode_attention_params c = q;
+    c.workspace = nullptr;
+    c.workspace_bytes = 0;
+    if (pl.splits > 1)
+    {
+        // what THIS call's partials take (not the max-shape bound of the workspace query)
+        const size_t need = (size_t) q.batch * q.num_heads * pl.splits * (q.head_size + 2) * sizeof(float);
+        MQ_CHECK(need <= DECODE_SCRATCH_BYTES,
+            "split-KV partials of this call (%zu bytes: batch %d x %d heads x %d splits) exceed the %zu-byte static scratch; "
+            "use mi355q_masked_multihead_attention with a workspace",
+            need, q.batch, q.num_heads, pl.splits, DECODE_SCRATCH_BYTES);
+        c.workspace = decode_scratch_of_current_device();
+        c.workspace_bytes = DECODE_SCRATCH_BYTES;
+    }
+    // every partial the merge reads is written by this call's main kernel first: nothing has to start at zero
+    masked_multihead_attention(c, stream);
 }
 
 } // namespace mi355q

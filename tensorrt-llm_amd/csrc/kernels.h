@@ -86,6 +86,8 @@ void ipc_close_handle(void* ptr);
 // decode_attn.hip
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q);
 void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream);
+size_t decode_attention_static_scratch_bytes();
+void masked_multihead_attention_static(const mi355q_decode_attention_params& q, hipStream_t stream);
 
 // context_attn.hip
 size_t context_attention_workspace_size(const mi355q_context_attention_params& q);

@@ -1694,6 +1694,21 @@ extern "C"
             });
     }
 
+    size_t mi355q_decode_attention_static_scratch_size(void)
+    {
+        return decode_attention_static_scratch_bytes();
+    }
+
+    mi355q_status mi355q_masked_multihead_attention_static(const mi355q_decode_attention_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                masked_multihead_attention_static(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
     size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params)
     {
         size_t res = 0;

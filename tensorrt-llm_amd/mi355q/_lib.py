@@ -168,6 +168,8 @@ SYMBOLS = {
     "mi355q_quantize_e4m3": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_decode_attention_workspace_size": (_sz, [C.POINTER(DecodeAttentionParams)]),
     "mi355q_masked_multihead_attention": (_i32, [C.POINTER(DecodeAttentionParams), _vp]),
+    "mi355q_decode_attention_static_scratch_size": (_sz, []),
+    "mi355q_masked_multihead_attention_static": (_i32, [C.POINTER(DecodeAttentionParams), _vp]),
     "mi355q_context_attention_workspace_size": (_sz, [C.POINTER(ContextAttentionParams)]),
     "mi355q_context_attention": (_i32, [C.POINTER(ContextAttentionParams), _vp]),
     "mi355q_allreduce_select_implementation": (_i32, [_sz, _i32, _sz]),
