@@ -376,24 +376,25 @@ def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64
 
 
 def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
-    """The oracle (CPU port of the MMHA math) on the same workload shape (`seqs` of the 64 sequences
-    x 32 heads x ctx 2048), timed on the host cores torch uses; best of `reps` passes (bounded to a
-    few tens of seconds)."""
+    """The oracle's C / OpenMP port of the MMHA math (oracle.c orc_decode_attention_16) on the same workload shape
+    (`seqs` of the 64 sequences x 32 heads x ctx 2048), timed on the host cores of the GPU box (one GPU's share: 16);
+    best of `reps` passes, bounded to a few tens of seconds."""
     import oracle
     torch.manual_seed(42)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box gives one GPU's share: 16 CPUs
+    cores = min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     cache = oracle.PagedKVCache(seqs, H, D, ctx, tpb, torch.bfloat16)
     cache.pool.copy_((torch.randn(cache.pool.shape) * 0.5).to(torch.bfloat16))
     qkv = torch.randn(seqs, 3 * H * D).to(torch.bfloat16)
     best = float("inf")
     for _ in range(reps):
         t0 = time.perf_counter()
-        oracle.decode_attention(qkv, cache, [ctx] * seqs, H, H, D, rope="neox", rot_dim=D, update_cache=False)
+        oracle.decode_attention_c(qkv, cache, [ctx] * seqs, H, H, D, rope="neox")
         best = min(best, time.perf_counter() - t0)
     nbytes = seqs * (2 * H * ctx * D * 2 + 3 * H * D * 2 + H * D * 2 + 2 * H * D * 2)
-    return {"value": nbytes / best / 1e9, "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{seqs} of 64 sequences x {H} heads x ctx {ctx}, oracle.decode_attention, "
-                      f"best of {reps} passes = {best:.2f} s"}
+    return {"value": nbytes / best / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"{seqs} of 64 sequences x {H} heads x ctx {ctx}, oracle.c orc_decode_attention_16 (C, OpenMP, "
+                      f"{cores} threads), best of {reps} passes = {best:.2f} s"}
 
 
 def main():
@@ -458,12 +459,18 @@ def main():
             with open(tfile) as f:
                 tj = json.load(f)
             res["roofline"]["traffic"] = tj.get("decode_attn_kernel_bytes_per_launch")
-            res["roofline"]["traffic_source"] = tj.get("source")
+            # NOT measured in this run: PMC passes are separate rocprofv3 runs of this same command (tools/run_round.sh)
+            res["roofline"]["traffic_from"] = "profiles/hbm_traffic.json (earlier builder-side PMC run: " + str(tj.get("source")) + ")"
         if not args.no_secondary and world == 1:  # side measurements and the CPU baseline: N = 1 only
             sec = {}
             try:
+                # launch floor (tools/lab_skel.hip): an empty 256-workgroup launch in a stream of launches is 1.65 us and
+                # streaming 8 MiB + an LDS reduce + the store 3.0 us, so cfg1 (8.9 MB) cannot exceed ~37 % of 8 TB/s per
+                # launch; the fused shapes (qkv 12288, gate|up 22016: GEMVs that share their input, N concatenated) amortise it
                 sec["w4a16_gemv"] = [bench_gemv(dev, 4 * 72, m=1), bench_gemv(dev, 4 * 72, m=1, pre_quant=True),
-                                     bench_gemv(dev, 4 * 72, m=16),
+                                     bench_gemv(dev, 4 * 72, m=4), bench_gemv(dev, 4 * 72, m=16),
+                                     bench_gemv(dev, 2 * 72, m=1, n=12288, k=4096, sets=24),
+                                     bench_gemv(dev, 2 * 72, m=1, n=22016, k=4096, sets=14),
                                      bench_gemv(dev, 2 * 72, m=1, n=11008, k=4096, sets=24),
                                      bench_gemv(dev, 2 * 72, m=1, n=4096, k=11008, sets=24),
                                      bench_gemv(dev, 48, m=1, n=28672, k=8192, sets=6),

@@ -423,6 +423,22 @@ def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_
     return out.to(T)
 
 
+def decode_attention_c(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_scaling=1.0, rope=None):
+    """The same generation step through oracle.c's plain C / OpenMP loops (orc_decode_attention_16): 16-bit caches,
+    NeoX RoPE over the whole head or none, no bias, cache not updated.  What bench.py's cpu_baseline leg times."""
+    assert cache.dtype == qkv.dtype and rope in (None, "neox")
+    B = qkv.shape[0]
+    out = np.empty((B, num_heads * head_dim), np.float32)
+    q16 = np.ascontiguousarray(_bits16(qkv.contiguous()))
+    pool16 = np.ascontiguousarray(_bits16(cache.pool.contiguous().view(-1)))
+    offs = np.ascontiguousarray(cache.offsets().numpy().astype(np.int64))
+    lens = np.ascontiguousarray(np.asarray(seq_lens, np.int32))
+    lib().orc_decode_attention_16(_p(q16), _p(pool16), _p(offs), _p(lens), _p(out), _i(B), _i(num_heads), _i(num_kv_heads),
+                                  _i(head_dim), _i(cache.max_blocks), _i(cache.tpb), _i(torch_dtype_code(qkv.dtype)),
+                                  _i(1 if rope == "neox" else 0), _c.c_float(q_scaling))
+    return torch.from_numpy(out).to(qkv.dtype)
+
+
 # ----------------------------------------------------------------------------- context attention
 def apply_rope_rows(x, positions, rot_dim, kind, base=10000.0, scale=1.0):
     """apply_rope over rows: x float32 numpy [S, H, Dh], positions int [S] (same pairing / angle rule)."""

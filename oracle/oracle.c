@@ -504,3 +504,86 @@ void orc_quantize_per_token(const float* x, int8_t* q, float* scale, size_t M, s
         scale[m] = amax / 127.f;
     }
 }
+
+/* ---------------------------------------------------------------- decode attention (C / OpenMP)
+ * The masked-MHA math of oracle.decode_attention (decoderMaskedMultiheadAttentionTemplate.h:1755-1813, 1988-2036,
+ * 2246-2313, Logit_value_fma :954-999) for a 16-bit paged cache with NeoX RoPE, as plain loops: bench.py's cpu_baseline
+ * leg times this one (the Python version spends its time in the interpreter).  pool: 16-bit elements; offsets
+ * [B][2][max_blocks] element offsets of the K / V blocks ([Hkv][tokens_per_block][Dh] each, kvCacheUtils.h:101-152).
+ * seq_lens include the current token; the new K/V are NOT appended (update_cache = False).  out: fp32 [B][Hq*Dh]. */
+void orc_decode_attention_16(const uint16_t* qkv, const uint16_t* pool, const int64_t* offsets, const int32_t* seq_lens,
+    float* out, int B, int Hq, int Hkv, int D, int max_blocks, int tpb, int dtype, int rope_neox, float q_scaling)
+{
+    const int grp = Hq / Hkv;
+    const float inv_sqrt = 1.0f / (sqrtf((float) D) * q_scaling);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < Hq; ++h)
+        {
+            const int hk = h / grp;
+            const int tl = seq_lens[b] - 1;
+            const uint16_t* row = qkv + (size_t) b * (Hq + 2 * Hkv) * D;
+            float* q = (float*) malloc(sizeof(float) * 3 * D);
+            float *k = q + D, *v = k + D;
+            for (int d = 0; d < D; ++d)
+            {
+                q[d] = from16(row[h * D + d], dtype);
+                k[d] = from16(row[(Hq + hk) * D + d], dtype);
+                v[d] = from16(row[(Hq + Hkv + hk) * D + d], dtype);
+            }
+            if (rope_neox)
+            {
+                const int half = D / 2;
+                for (int i = 0; i < half; ++i)
+                {
+                    const float ang = (float) tl / powf(10000.0f, (float) (2 * i) / (float) D);
+                    const float c = cosf(ang), s = sinf(ang);
+                    const float qa = q[i], qb = q[i + half], ka = k[i], kb = k[i + half];
+                    q[i] = from16(to16(c * qa - s * qb, dtype), dtype);
+                    q[i + half] = from16(to16(c * qb + s * qa, dtype), dtype);
+                    k[i] = from16(to16(c * ka - s * kb, dtype), dtype);
+                    k[i + half] = from16(to16(c * kb + s * ka, dtype), dtype);
+                }
+            }
+            float* logit = (float*) malloc(sizeof(float) * (tl + 1));
+            float mx = -INFINITY;
+            for (int t = 0; t <= tl; ++t)
+            {
+                double acc = 0.0;
+                if (t < tl)
+                {
+                    const uint16_t* kr = pool + offsets[((size_t) b * 2 + 0) * max_blocks + t / tpb]
+                        + ((size_t) hk * tpb + t % tpb) * D;
+                    for (int d = 0; d < D; ++d)
+                        acc += (double) q[d] * (double) from16(kr[d], dtype);
+                }
+                else
+                    for (int d = 0; d < D; ++d)
+                        acc += (double) q[d] * (double) k[d];
+                logit[t] = (float) acc * inv_sqrt;
+                mx = logit[t] > mx ? logit[t] : mx;
+            }
+            double* o = (double*) calloc(D, sizeof(double));
+            float sum = 0.f;
+            for (int t = 0; t <= tl; ++t)
+            {
+                const float p = expf(logit[t] - mx);
+                sum += p;
+                if (t < tl)
+                {
+                    const uint16_t* vr = pool + offsets[((size_t) b * 2 + 1) * max_blocks + t / tpb]
+                        + ((size_t) hk * tpb + t % tpb) * D;
+                    for (int d = 0; d < D; ++d)
+                        o[d] += (double) p * (double) from16(vr[d], dtype);
+                }
+                else
+                    for (int d = 0; d < D; ++d)
+                        o[d] += (double) p * (double) v[d];
+            }
+            for (int d = 0; d < D; ++d)
+                out[((size_t) b * Hq + h) * D + d] = (float) o[d] / (sum + 1e-6f);
+            free(o);
+            free(logit);
+            free(q);
+        }
+}

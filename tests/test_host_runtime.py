@@ -34,10 +34,11 @@ def test_blocks_manager_pointer_layout_and_reuse():
     assert bm.get_number_blocks(s0) == 2
     bm.free(s0)
     assert len(bm.free_blocks) == 5 and [b.idx for b in bm.free_blocks] == [3, 4, 5, 0, 2]
-    for _ in range(5):
-        bm.allocate(s1)
+    for i in range(5):
+        bm.allocate(GenerationSequence(20 + i, 1 + i))
+    assert not bm.has_free_block()
     with pytest.raises(RuntimeError, match="Can't allocate new block"):
-        bm.allocate(s1)
+        bm.allocate(GenerationSequence(30, 6))
 
 
 def test_kv_cache_manager_context_and_steps():
@@ -73,8 +74,8 @@ def test_kv_cache_manager_sink_bubble_and_beams():
     s = GenerationSequence(7, 0)
     mgr.add_sequence(s, context_len=5)    # 5 + bubble 2 = 7 tokens -> 2 blocks, the last one not shared across beams
     beams = mgr.blocks_manager.allocated_blocks[s]
-    assert beams[0][0] is beams[1][0] and beams[0][0].is_shared()
-    assert beams[0][1] is not beams[1][1]
+    assert beams[0][0].idx == beams[1][0].idx and beams[0][0].is_shared()
+    assert beams[0][1].idx != beams[1][1].idx and not beams[0][1].is_shared()
     ptr = mgr.get_block_pointers(2)
     assert ptr.shape == (1, 1, 2, 2, 8) and ptr[0, 0, 0, 0, 0] == ptr[0, 0, 1, 0, 0] and ptr[0, 0, 0, 0, 1] != ptr[0, 0, 1, 0, 1]
 

@@ -211,3 +211,18 @@ def test_decode_attention_reference_against_plain_softmax():
             p = torch.softmax((K @ qkv[b, h * D:(h + 1) * D].float()) / D ** 0.5, 0)
             ref = p @ V
             assert torch.allclose(out[b, h * D:(h + 1) * D].float(), ref, atol=2e-3)
+
+
+def test_c_decode_attention_agrees_with_python_oracle():
+    # bench.py's cpu_baseline leg times the C / OpenMP loop; it must be the same math as oracle.decode_attention
+    torch.manual_seed(0)
+    B, H, Hkv, D, ctx, tpb = 3, 8, 2, 128, 300, 64
+    for dt in (torch.bfloat16, torch.float16):
+        cache = oracle.PagedKVCache(B, Hkv, D, ctx, tpb, dt)
+        cache.pool.copy_((torch.randn(cache.pool.shape) * 0.5).to(dt))
+        qkv = torch.randn(B, (H + 2 * Hkv) * D).to(dt)
+        lens = [300, 17, 1]
+        for rope in (None, "neox"):
+            a = oracle.decode_attention(qkv, cache, lens, H, Hkv, D, rope=rope, rot_dim=D if rope else 0, update_cache=False)
+            b = oracle.decode_attention_c(qkv, cache, lens, H, Hkv, D, rope=rope)
+            assert (a.float() - b.float()).abs().max().item() <= (2e-3 if dt == torch.float16 else 8e-3)
