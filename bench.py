@@ -11,7 +11,9 @@ resident in HBM before the timed region.  Secondary numbers of the same metric f
 GB/s with >= 64 rotating weight sets, SmoothQuant int8 GEMM TOP/s) ride along under "secondary".
 
 N>1: attention shards by KV head / sequence with no collective -> every rank runs the
-same per-GPU workload on its own cache, weak scaling, no data-path collective.
+same per-GPU workload on its own cache, weak scaling, no data-path collective in the headline.  The path's one real
+exchange step -- the all-reduce behind a row-parallel GEMM -- rides along as `secondary.tp_row_parallel_gemm_allreduce`
+(custom push all-reduce and RCCL, all ranks take part).
 """
 import argparse
 import json
@@ -126,6 +128,12 @@ def bench_decode_attention(dev, steps, B=64, Hq=8, Hkv=1, D=128, ctx=2048, tpb=6
             "kv_cache": kv, "us_per_call": dev_s / steps * 1e6, "GBps": algo / (dev_s / steps) / 1e9,
             "frac_of_8TBps": algo / (dev_s / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo, "cache_sets": sets,
             "launches": launches}
+
+
+def trace(msg):
+    """Stage markers on stderr (MI355Q_BENCH_TRACE=1): where a multi-rank run stands."""
+    if os.environ.get("MI355Q_BENCH_TRACE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
 def time_steps(fn, steps, warmup, barrier):
@@ -375,6 +383,112 @@ def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64
             "frac_of_bf16_peak": flops / (dev_s / steps) / 1e12 / 2500.0}
 
 
+def bench_tp_row_parallel(dev, world, rank, iters=40):
+    """cfg4's exchange step: the row-parallel W4A16 GEMM of Llama-2-70B's down projection under TP = 8
+    (K_local 3584 -> N 8192, g = 128) followed by the all-reduce of its [M, 8192] bf16 output, M in {1, 8, 64}: through
+    the custom push all-reduce (csrc/allreduce.hip, AUTO strategy) and through RCCL (torch.distributed).  Every rank
+    takes part; times are the max over ranks.  bus GB/s = 2 (N - 1) / N * bytes / time (per-link bound 153 GB/s for a
+    ring, 7 links in parallel for the direct exchange).  World 1: the GEMM alone (the all-reduce is the identity)."""
+    from mi355q import _lib as L
+    from mi355q import functional as F
+    import ctypes as C
+    torch.manual_seed(100 + rank)
+    dt, k, n, g = torch.bfloat16, 3584, 8192, 128
+    w = torch.randint(-128, 128, (k, n // 2), dtype=torch.int8, device=dev)
+    scale = torch.rand(k // g, n, dtype=dt, device=dev)
+    zero = torch.randn(k // g, n, dtype=dt, device=dev)
+
+    def agree(ok):  # every rank learns whether all ranks got through the stage (keeps the collectives matched)
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    helper, err = None, None
+    trace("tp leg: start")
+    if world > 1:
+        try:
+            from mi355q.ipc import CustomAllReduceHelper
+            helper = CustomAllReduceHelper()
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        if not agree(helper is not None):
+            helper, err = None, err or "a peer rank could not map the IPC buffers"
+    out = []
+    trace(f"tp leg: helper {'ready' if helper is not None else err}")
+    for m in (1, 8, 64):
+        trace(f"tp leg: m = {m}")
+        act = torch.randn(m, k, dtype=dt, device=dev)
+        y = torch.empty(m, n, dtype=dt, device=dev)
+        ws_bytes = L.lib().mi355q_weight_only_gemm_workspace_size(m, n, k, L.WEIGHT_INT4)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        p = L.WeightOnlyParams()
+        p.qweight, p.scales, p.zeros = w.data_ptr(), scale.data_ptr(), zero.data_ptr()
+        p.in_, p.act_scale, p.bias, p.out = act.data_ptr(), None, None, y.data_ptr()
+        p.m, p.n, p.k, p.group_size = m, n, k, g
+        p.weight_type, p.act_type = L.WEIGHT_INT4, L.BF16
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
+
+        def gemm():
+            rc = L.lib().mi355q_weight_only_gemm(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, L.lib().mi355q_last_error()
+
+        def timed(fn):
+            bar = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+            _, dev_s = time_steps(fn, iters, 3, bar)
+            t = torch.tensor([dev_s], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item() / iters * 1e6
+
+        nbytes = m * n * 2
+        line = {"m": m, "k_local": k, "n": n, "message_bytes": nbytes, "gemm_us": timed(gemm)}
+        trace("tp leg: gemm timed")
+        if world == 1:
+            line["allreduce"] = "identity (world 1)"
+        else:
+            bus = lambda us: 2.0 * (world - 1) / world * nbytes / (us * 1e-6) / 1e9
+            red = torch.empty_like(y)
+
+            def rccl():
+                gemm()
+                red.copy_(y)
+                dist.all_reduce(red)
+            def rccl_only():
+                dist.all_reduce(red)
+            if dist.get_backend() == "nccl":
+                line["gemm_plus_rccl_us"] = timed(rccl)
+                trace("tp leg: rccl timed")
+                t = timed(rccl_only)
+                line["rccl_allreduce_us"], line["rccl_bus_GBps"] = t, bus(t)
+            else:
+                line["rccl"] = "skipped: one-GPU rehearsal on gloo"
+            if helper is not None:
+                ok = True
+                try:
+                    def custom():
+                        gemm()
+                        helper.allreduce(y, out=red, direct=True)
+                    def custom_only():
+                        helper.allreduce(y, out=red, direct=True)
+                    line["gemm_plus_custom_us"] = timed(custom)
+                    t = timed(custom_only)
+                    line["custom_allreduce_us"], line["custom_bus_GBps"] = t, bus(t)
+                    line["custom_strategy"] = {1: "oneshot", 2: "twoshot", 0: "ring"}[
+                        L.lib().mi355q_allreduce_select_implementation(nbytes, world, helper.size)]
+                    ok = not helper.timed_out()
+                except Exception as e:  # noqa: BLE001
+                    ok, line["custom_error"] = False, repr(e)
+                if not agree(ok):
+                    line.setdefault("custom_error", "a wait for a peer rank timed out")
+                    helper = None   # the flags are no longer in step: RCCL only from here on
+            elif err:
+                line["custom_error"] = err
+        out.append(line)
+    return out
+
+
 def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
     """The oracle's C / OpenMP port of the MMHA math (oracle.c orc_decode_attention_16) on the same workload shape
     (`seqs` of the 64 sequences x 32 heads x ctx 2048), timed on the host cores of the GPU box (one GPU's share: 16);
@@ -404,6 +518,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-secondary", action="store_true", help="skip the GEMV / int8 GEMM side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tp", action="store_true", help="skip the row-parallel GEMM + all-reduce leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -411,17 +526,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation (no CPU fallback)")
+    # rehearsal on a one-GPU box (MI355Q_BENCH_ONE_GPU=1): every rank on device 0, gloo instead of RCCL -- exercises the
+    # multi-rank code paths (IPC mapping, flags, matched collectives); its numbers mean nothing
+    one_gpu = os.environ.get("MI355Q_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         barrier = lambda: dist.barrier()
     else:
         barrier = lambda: None
 
     B, H, D, ctx, tpb = 64, 32, 128, 2048, 64
+    trace("headline: building the cache")
     plg, inputs, out, ws, algo_bytes, keep = build_attention_case(dev, B, H, D, ctx, tpb, seed=42 + rank)
+    trace("headline: timing")
     step = lambda: plg.enqueue(inputs, [out], ws)
     wall, dev_s = time_steps(step, args.steps, args.warmup, barrier)
 
@@ -429,6 +554,15 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, dev_max = t.tolist()
+
+    trace("headline: done")
+    # the path's one exchange step (row-parallel GEMM + all-reduce): every rank takes part, rank 0 reports
+    tp_lines = None
+    if not args.no_tp:
+        try:
+            tp_lines = bench_tp_row_parallel(dev, world, rank)
+        except Exception as e:  # noqa: BLE001 -- never takes the headline down
+            tp_lines = {"error": repr(e)}
 
     if rank == 0:
         per_launch = dev_s / args.steps
@@ -496,6 +630,8 @@ def main():
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)
             res["secondary"] = sec
+        if tp_lines is not None:
+            res.setdefault("secondary", {})["tp_row_parallel_gemm_allreduce"] = tp_lines
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_attention(H, D, ctx, tpb)
         print(json.dumps(res))

@@ -355,8 +355,14 @@ extern "C"
 
 #define MI355Q_MAX_RANKS_PER_NODE 8 /* kernels/customAllReduceKernels.h:33 */
 #define MI355Q_IPC_HANDLE_BYTES 64  /* sizeof(hipIpcMemHandle_t) */
-    /* kernels/customAllReduceKernels.h:44-58 AllReduceParams (+ timeout_flag: the flag spins are bounded here; a
-     * device word that receives 1 when a peer never arrived, or NULL) */
+#define MI355Q_AR_MAX_WORKGROUPS 256 /* one per CU (the reference: MAX_ALL_REDUCE_BLOCKS = 24, customAllReduceKernels.h:32) */
+    /* bytes of ONE barrier-flag array (barrier-in or barrier-out) per rank: flags are per (phase, source rank,
+     * workgroup); replaces IPC_BARRIERS_SIZE_PER_GPU of tensorrt_llm/_ipc_utils.py */
+    size_t mi355q_allreduce_barrier_bytes(void);
+    /* kernels/customAllReduceKernels.h:44-58 AllReduceParams, plus what the MI355X kernels add (trailing fields):
+     * the input where it lies (they push it to the peers themselves: no staging copy), the byte size of a comm buffer
+     * (checked against the message), a host-visible word that receives 1 when a peer never arrived (or NULL) and the
+     * wall-clock bound of every wait in milliseconds (0 = 2000). */
     typedef struct
     {
         size_t elts_total;
@@ -370,18 +376,28 @@ extern "C"
         void* peer_comm_buffer_ptrs[MI355Q_MAX_RANKS_PER_NODE];
         void* local_output_buffer_ptr;
         uint32_t* timeout_flag;
+        const void* local_input_buffer_ptr;
+        size_t comm_buffer_bytes; /* 0 = mi355q_allreduce_max_workspace_size(ranks_per_node) */
+        uint32_t timeout_ms;
     } mi355q_allreduce_params;
     /* AllReduceParams::deserialize(buffer, tpSize, tpRank, flag_value) (customAllReduceKernels.cu:398-425):
      * buffer_ptrs = HOST array [4 * tpSize]: ping buffers | pong buffers | barrier-in | barrier-out, one per rank */
     mi355q_status mi355q_allreduce_params_deserialize(mi355q_allreduce_params* out, const void* const* buffer_ptrs,
         size_t tpSize, size_t tpRank, uint32_t flag_value);
-    /* customAllReduce(params, data, elts, size_per_elem, dataType, strat, stream) (:427-454): one-shot / two-shot sum
-     * over the peers' comm buffers into `data`; the caller has copied its input into peer_comm_buffer_ptrs[rank]
-     * (allreducePlugin.cpp:195-199).  dtype MI355Q_FLOAT / HALF / BF16; strategy MI355Q_AR_ONESHOT / TWOSHOT. */
+    /* customAllReduce(params, data, elts, size_per_elem, dataType, strat, stream) (:427-454): one-shot / two-shot sum of
+     * params->local_input_buffer_ptr over the ranks into `data` (in place allowed).  The reference has the caller copy
+     * its input into peer_comm_buffer_ptrs[rank] first (allreducePlugin.cpp:195-199); here the kernel pushes it into
+     * the peers' buffers itself.  dtype MI355Q_FLOAT / HALF / BF16; strategy MI355Q_AR_ONESHOT / TWOSHOT.  Capacity:
+     * one-shot ranks * roundup(bytes, 256) <= comm_buffer_bytes, two-shot 2 * bytes <= comm_buffer_bytes. */
     mi355q_status mi355q_custom_all_reduce(mi355q_allreduce_params* params, void* data, size_t elts, int32_t dtype,
         int32_t strategy, void* stream);
     /* invokeMultiGpuBarrier (:391-394) over peer_barrier_ptrs_out */
     mi355q_status mi355q_multi_gpu_barrier(const mi355q_allreduce_params* params, void* stream);
+    /* No counterpart in the reference (its flag spins are unbounded): a zeroed host-visible word for
+     * mi355q_allreduce_params.timeout_flag / the AllReduce plugin's workspace table; the kernels set it to 1 when a
+     * wait for a peer ran out of time (their output is then NaN), the host may read it at any time. */
+    mi355q_status mi355q_allreduce_alloc_timeout_flag(uint32_t** flag);
+    mi355q_status mi355q_allreduce_free_timeout_flag(uint32_t* flag);
     /* IpcMemory (tensorrt_llm/_ipc_utils.py:66-133; cpp/tensorrt_llm/runtime/ipcUtils.cpp): set-up time helpers --
      * allocate a zeroed fine-grained device buffer, export / import it across the ranks' processes.  These are the
      * only entry points that allocate device memory. */

@@ -1,14 +1,29 @@
-// allreduce.hip -- the custom all-reduce of the TP row-parallel GEMM outputs:
-// kernels/customAllReduceKernels.cu:108-291 (multi_gpu_barrier, oneShotAllReduceKernel, twoShotAllReduceKernel),
-// :295-352 kernelLaunchConfig, :398-454 AllReduceParams::deserialize / customAllReduce; the IPC buffer set-up of
-// tensorrt_llm/_ipc_utils.py:66-133 (IpcMemory) is exposed as mi355q_ipc_*.
-// Every rank owns a communication buffer and two barrier-flag arrays that its peers map through HIP IPC (xGMI peer
-// access between GPUs of one node).  One-shot: after a flag barrier every rank reads all peers' buffers and sums them
-// in T arithmetic, starting from its own rank (the reference's order, so results match it bit for bit).  Two-shot:
-// reduce-scatter into the owner's buffer, per-block release/acquire flag barrier, all-gather.
-// Differences from the reference, on purpose: flags are read / written with system-scope atomics (and the buffers are
-// allocated fine-grained) because a spinning kernel on CDNA only observes a peer's store through them; spins are
-// bounded (about a second) and report through `timeout_flag` instead of hanging the GPU.
+// allreduce.hip -- the custom all-reduce behind the TP row-parallel GEMMs.  It answers the
+// reference's contract -- AllReduceParams, customAllReduce(params, data, elts, dtype, strategy), the ONESHOT / TWOSHOT
+// strategies and their summation order (kernels/customAllReduceKernels.cu:137-291, :398-454; the IpcMemory set-up of
+// tensorrt_llm/_ipc_utils.py:66-133 is mi355q_ipc_*) -- with an MI355X design:
+//   * PUSH, not pull.  xGMI is point to point (7 links per GPU) and a remote load is a full round trip that holds a
+//     wave's memory queue, while remote stores are posted: every rank WRITES its contribution into a slot of each
+//     peer's buffer (all 7 links busy at once), raises a flag there, and each rank then reduces out of its OWN HBM.
+//     The input is read where it lies: no staging copy into the rank's own buffer, one launch per all-reduce.
+//   * workgroup w of every rank owns byte range w of the message (one-shot) or of every slice (two-shot) and only ever
+//     waits for workgroup w of its peers -- flags are per (phase, source rank, workgroup) -- so there is no grid-wide
+//     step inside a rank, no dependence between workgroups of one launch (any number may be resident), and up to 256
+//     workgroups (one per CU, 4 KiB each at 1 MiB) take part instead of the reference's 24 blocks.
+//   * hand-off as the microarchitecture guide prescribes for data another agent reads: 16-byte write-through stores
+//     (sc0 sc1: system scope) into fine-grained memory, every storing wave drains `vmcnt(0)`, workgroup barrier, ONE
+//     lane per peer stores the flag (system-scope atomic store); the consumer polls its own flag words with relaxed
+//     system-scope loads and reads the payload with sc0 sc1 loads (peers wrote it behind this GPU's L2).
+//   * flags carry the call counter and are compared with `>=` (a peer may already be one call ahead and have
+//     overwritten the word); the payload alternates between the ping and pong buffers so that a rank one call ahead
+//     never overwrites bytes a slower rank still reads.
+//   * every wait is bounded by the wall clock (s_memrealtime; params.timeout_ms, default 2 s).  On expiry the kernel
+//     sets *timeout_flag (host-visible, mi355q_allreduce_alloc_timeout_flag) and POISONS its output with NaN instead
+//     of summing stale bytes; the plugin refuses further work once the flag is set.
+// Summation order (bit-exact with the reference, checked against oracle.custom_all_reduce): one-shot adds the ranks'
+// values in T arithmetic starting from the reading rank, two-shot from the slice's owner.
+// Capacity of a comm buffer of W bytes: one-shot ranks * roundup(S, 256) <= W, two-shot 2 S <= W; beyond that the
+// host side uses RCCL (RING).
 #include "kernels.h"
 #include <algorithm>
 #include <cstring>
@@ -18,195 +33,231 @@ namespace mi355q
 namespace
 {
 
-constexpr int AR_MAX_BLOCKS = 24;   // MAX_ALL_REDUCE_BLOCKS, customAllReduceKernels.h:32
-constexpr int AR_BLOCK_SIZE = 1024; // DEFAULT_BLOCK_SIZE
-constexpr int AR_WAVE = 64;
-constexpr uint32_t AR_SPIN_LIMIT = 1u << 24; // x s_sleep: about a second
-
-__device__ __forceinline__ void st_flag_release(uint32_t flag, uint32_t* addr)
-{
-    __hip_atomic_store(addr, flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ uint32_t ld_flag_acquire(uint32_t* addr)
-{
-    return __hip_atomic_load(addr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void st_flag_relaxed(uint32_t flag, uint32_t* addr)
-{
-    __hip_atomic_store(addr, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ uint32_t ld_flag_relaxed(uint32_t* addr)
-{
-    return __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// spin until *addr == flag; false on timeout
-template <bool ACQUIRE>
-__device__ __forceinline__ bool wait_flag(uint32_t* addr, uint32_t flag)
-{
-    for (uint32_t i = 0; i < AR_SPIN_LIMIT; ++i)
-    {
-        if ((ACQUIRE ? ld_flag_acquire(addr) : ld_flag_relaxed(addr)) == flag)
-            return true;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    return false;
-}
-
-// customAllReduceKernels.cu:108-129: on return at least block 0 of every rank has reached this point
-__device__ __forceinline__ void multi_gpu_barrier(
-    uint32_t* const* signals, uint32_t flag, int rank, int world, int tidx, int bidx, uint32_t* timeout_flag)
-{
-    if (tidx < world)
-    {
-        if (bidx == 0)
-            st_flag_relaxed(flag, signals[tidx] + rank);
-        if (!wait_flag<false>(signals[rank] + tidx, flag) && timeout_flag)
-            *timeout_flag = 1;
-    }
-    __syncthreads();
-}
+constexpr int AR_THREADS = 256;
+constexpr int AR_MAX_WGS = MI355Q_AR_MAX_WORKGROUPS;
+constexpr size_t AR_MIN_CHUNK = 4096; // bytes per workgroup before another workgroup is worth its flags
+constexpr int AR_SC_SYSTEM = 17;      // buffer aux bits: sc0 (1) | sc1 (16)
 
 typedef __attribute__((ext_vector_type(2))) _Float16 ar_f16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t ar_u32x4;
+typedef __attribute__((address_space(1))) uint32_t ar_gu32;
 
-// add128b (:98-106): element-wise add of two 16-byte packs in T arithmetic (each add rounds to T)
+// element-wise add of two 16-byte packs in T arithmetic: each add rounds to T (add128b, customAllReduceKernels.cu:98-106)
 template <typename T>
-__device__ __forceinline__ uint4 add_pack(const uint4& a, const uint4& b);
-template <>
-__device__ __forceinline__ uint4 add_pack<float>(const uint4& a, const uint4& b)
+__device__ __forceinline__ ar_u32x4 add_pack(const ar_u32x4& a, const ar_u32x4& b);
+__device__ __forceinline__ uint32_t add_f32(uint32_t a, uint32_t b)
 {
-    return make_uint4(__float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x)),
-        __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y)),
-        __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z)),
-        __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w)));
+    return __float_as_uint(__uint_as_float(a) + __uint_as_float(b));
 }
 __device__ __forceinline__ uint32_t add_h2(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ar_f16x2, a) + __builtin_bit_cast(ar_f16x2, b));
 }
-template <>
-__device__ __forceinline__ uint4 add_pack<f16_t>(const uint4& a, const uint4& b)
-{
-    return make_uint4(add_h2(a.x, b.x), add_h2(a.y, b.y), add_h2(a.z, b.z), add_h2(a.w, b.w));
-}
 __device__ __forceinline__ uint32_t add_bf2(uint32_t a, uint32_t b)
 {
-    // gfx950 has no packed bf16 add: widen, add in fp32, round to nearest even
+    // gfx950 has no packed bf16 add: widen, add in fp32, round to nearest even (the value a bf16 add returns)
     return pack2<bf16_t>(T16<bf16_t>::lo(a) + T16<bf16_t>::lo(b), T16<bf16_t>::hi(a) + T16<bf16_t>::hi(b));
 }
 template <>
-__device__ __forceinline__ uint4 add_pack<bf16_t>(const uint4& a, const uint4& b)
+__device__ __forceinline__ ar_u32x4 add_pack<float>(const ar_u32x4& a, const ar_u32x4& b)
 {
-    return make_uint4(add_bf2(a.x, b.x), add_bf2(a.y, b.y), add_bf2(a.z, b.z), add_bf2(a.w, b.w));
+    return ar_u32x4{add_f32(a.x, b.x), add_f32(a.y, b.y), add_f32(a.z, b.z), add_f32(a.w, b.w)};
+}
+template <>
+__device__ __forceinline__ ar_u32x4 add_pack<f16_t>(const ar_u32x4& a, const ar_u32x4& b)
+{
+    return ar_u32x4{add_h2(a.x, b.x), add_h2(a.y, b.y), add_h2(a.z, b.z), add_h2(a.w, b.w)};
+}
+template <>
+__device__ __forceinline__ ar_u32x4 add_pack<bf16_t>(const ar_u32x4& a, const ar_u32x4& b)
+{
+    return ar_u32x4{add_bf2(a.x, b.x), add_bf2(a.y, b.y), add_bf2(a.z, b.z), add_bf2(a.w, b.w)};
 }
 
 template <typename T>
-struct ArElem
+__device__ __forceinline__ ar_u32x4 nan_pack()
 {
-    static constexpr int SIZE = sizeof(float) == sizeof(T) ? 4 : 2;
-};
+    constexpr uint32_t v = sizeof(T) == 4 ? 0x7fc00000u : 0x7fff7fffu; // 0x7fff is a NaN in fp16 and in bf16
+    return ar_u32x4{v, v, v, v};
+}
 
 struct ArArgs
 {
-    size_t elts_total, elts_per_rank, elts_per_block, rank_offset;
+    size_t total_bytes; // the message
+    size_t chunk_bytes; // per workgroup: of the message (one-shot) or of a slice (two-shot); a multiple of 16
+    size_t slot_bytes;  // one-shot: stride of the ranks' slots in a comm buffer; two-shot: bytes of a slice
     int ranks, rank;
-    uint32_t barrier_flag;
+    uint32_t flag;
     uint32_t* barrier_in[MI355Q_MAX_RANKS_PER_NODE];
     uint32_t* barrier_out[MI355Q_MAX_RANKS_PER_NODE];
     uint8_t* comm[MI355Q_MAX_RANKS_PER_NODE];
+    const uint8_t* in;
     uint8_t* out;
     uint32_t* timeout_flag;
+    uint64_t timeout_ticks; // s_memrealtime ticks (100 MHz)
 };
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ar_rsrc(const void* p, size_t bytes)
+{
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (u >> 32));
+    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t) (bytes > 0xffffffffull ? 0xffffffffull : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void*) (((uint64_t) hi << 32) | lo), 0, nb, 0x00020000);
+}
+
+__device__ __forceinline__ void flag_store(uint32_t* addr, uint32_t v)
+{
+    __hip_atomic_store((ar_gu32*) addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// poll *addr until it has reached `flag` (wrap-safe >=: the peer may be a call ahead); false when the clock runs out
+__device__ __forceinline__ bool flag_wait(uint32_t* addr, uint32_t flag, uint64_t timeout_ticks)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;)
+    {
+        const uint32_t v = __hip_atomic_load((ar_gu32*) addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t) (v - flag) >= 0)
+            return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks)
+            return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+// after a workgroup's stores into the peers: drain, barrier, one lane per peer raises this workgroup's flag of
+// `phase` there and waits for the peers' same flag here.  Returns false (block-uniform) if a peer never arrived.
+template <int RANKS>
+__device__ __forceinline__ bool publish_and_wait(const ArArgs& p, int phase, int w, int* failed_lds)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // EVERY storing wave, before the barrier the signalling lanes pass
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < RANKS)
+    {
+        flag_store(p.barrier_in[tid] + ((size_t) (phase * RANKS + p.rank) * AR_MAX_WGS + w), p.flag);
+        if (!flag_wait(p.barrier_in[p.rank] + ((size_t) (phase * RANKS + tid) * AR_MAX_WGS + w), p.flag, p.timeout_ticks))
+        {
+            if (p.timeout_flag)
+                __hip_atomic_store(p.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *failed_lds = 1;
+        }
+    }
+    __syncthreads();
+    return *failed_lds == 0;
+}
+
+// ONESHOT: push the workgroup's byte range into slot `rank` of every rank's buffer; then sum the RANKS slots of the own
+// buffer in the reference's order (own rank first).
+template <typename T, int RANKS>
+__global__ __launch_bounds__(AR_THREADS) void one_shot_push_kernel(ArArgs p)
+{
+    __shared__ int failed;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0)
+        failed = 0;
+    const size_t begin = (size_t) w * p.chunk_bytes;
+    const size_t end = min(begin + p.chunk_bytes, p.total_bytes);
+    __amdgpu_buffer_rsrc_t dst[RANKS], src[RANKS];
+#pragma unroll
+    for (int i = 0; i < RANKS; ++i)
+    {
+        dst[i] = ar_rsrc(p.comm[i] + (size_t) p.rank * p.slot_bytes, p.total_bytes);                         // my slot, at rank i
+        src[i] = ar_rsrc(p.comm[p.rank] + (size_t) ((p.rank + i) % RANKS) * p.slot_bytes, p.total_bytes);   // order of the sum
+    }
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+        const ar_u32x4 v = *reinterpret_cast<const ar_u32x4*>(p.in + off);
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(v, dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
+    }
+    const bool ok = publish_and_wait<RANKS>(p, 0, w, &failed);
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+        ar_u32x4 vals[RANKS];
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            vals[i] = __builtin_amdgcn_raw_buffer_load_b128(src[i], (uint32_t) off, 0, AR_SC_SYSTEM);
+        ar_u32x4 sum = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            sum = add_pack<T>(sum, vals[i]);
+        *reinterpret_cast<ar_u32x4*>(p.out + off) = ok ? sum : nan_pack<T>();
+    }
+}
+
+// TWOSHOT: reduce-scatter and all-gather, both pushed.  A comm buffer holds [RANKS scatter slots of one slice | the
+// gathered message]: (1) slice j of my input goes to scatter slot `rank` of rank j; (2) I sum the RANKS slots of my
+// slice (my own contribution first, customAllReduceKernels.cu:232-246) and push the result into every rank's gather
+// area; (3) the gather area is copied out.
+template <typename T, int RANKS>
+__global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
+{
+    __shared__ int failed;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0)
+        failed = 0;
+    const size_t slice = p.slot_bytes;
+    const size_t begin = (size_t) w * p.chunk_bytes;
+    const size_t end = min(begin + p.chunk_bytes, slice);
+    __amdgpu_buffer_rsrc_t scatter_dst[RANKS], scatter_src[RANKS], gather_dst[RANKS];
+#pragma unroll
+    for (int i = 0; i < RANKS; ++i)
+    {
+        scatter_dst[i] = ar_rsrc(p.comm[i] + (size_t) p.rank * slice, slice);
+        scatter_src[i] = ar_rsrc(p.comm[p.rank] + (size_t) ((p.rank + i) % RANKS) * slice, slice);
+        gather_dst[i] = ar_rsrc(p.comm[i] + (size_t) (RANKS + p.rank) * slice, slice);
+    }
+    const __amdgpu_buffer_rsrc_t gather_src = ar_rsrc(p.comm[p.rank] + (size_t) RANKS * slice, (size_t) RANKS * slice);
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+        {
+            const ar_u32x4 v = *reinterpret_cast<const ar_u32x4*>(p.in + (size_t) i * slice + off);
+            __builtin_amdgcn_raw_buffer_store_b128(v, scatter_dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
+        }
+    }
+    bool ok = publish_and_wait<RANKS>(p, 0, w, &failed);
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+        ar_u32x4 vals[RANKS];
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            vals[i] = __builtin_amdgcn_raw_buffer_load_b128(scatter_src[i], (uint32_t) off, 0, AR_SC_SYSTEM);
+        ar_u32x4 sum = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            sum = add_pack<T>(sum, vals[i]);
+        if (!ok)
+            sum = nan_pack<T>();
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(sum, gather_dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
+    }
+    ok = publish_and_wait<RANKS>(p, 1, w, &failed) && ok;
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+        {
+            const ar_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(gather_src, (uint32_t) ((size_t) i * slice + off), 0, AR_SC_SYSTEM);
+            *reinterpret_cast<ar_u32x4*>(p.out + (size_t) i * slice + off) = ok ? v : nan_pack<T>();
+        }
+    }
+}
+
+// invokeMultiGpuBarrier (customAllReduceKernels.cu:391-394): every rank has reached this point of its stream
 __global__ void multi_gpu_barrier_kernel(ArArgs p)
 {
-    multi_gpu_barrier(p.barrier_out, p.barrier_flag, p.rank, p.ranks, threadIdx.x, blockIdx.x, p.timeout_flag);
-}
-
-// :137-189
-template <typename T, int RANKS>
-__global__ __launch_bounds__(AR_BLOCK_SIZE) void one_shot_kernel(ArArgs p)
-{
-    constexpr int ES = ArElem<T>::SIZE, NUM_ELTS = 16 / ES;
-    const int bidx = blockIdx.x, tidx = threadIdx.x;
-    multi_gpu_barrier(p.barrier_in, p.barrier_flag, p.rank, RANKS, tidx, bidx, p.timeout_flag);
-    const uint8_t* src[RANKS];
-#pragma unroll
-    for (int ii = 0; ii < RANKS; ++ii)
-        src[ii] = p.comm[(p.rank + ii) % RANKS];
-    const size_t offset = (size_t) bidx * p.elts_per_block + (size_t) tidx * NUM_ELTS;
-    const size_t max_offset = min((size_t) (bidx + 1) * p.elts_per_block, p.elts_per_rank);
-    for (size_t it = offset; it < max_offset; it += (size_t) blockDim.x * NUM_ELTS)
+    const int tid = threadIdx.x;
+    if (tid < p.ranks)
     {
-        uint4 vals[RANKS];
-#pragma unroll
-        for (int ii = 0; ii < RANKS; ++ii)
-            vals[ii] = *reinterpret_cast<const uint4*>(src[ii] + it * ES);
-        uint4 sums = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int ii = 0; ii < RANKS; ++ii)
-            sums = add_pack<T>(sums, vals[ii]);
-        *reinterpret_cast<uint4*>(p.out + it * ES) = sums;
-    }
-}
-
-// :191-291
-template <typename T, int RANKS>
-__global__ __launch_bounds__(AR_BLOCK_SIZE) void two_shot_kernel(ArArgs p)
-{
-    constexpr int ES = ArElem<T>::SIZE, NUM_ELTS = 16 / ES;
-    const int bidx = blockIdx.x, tidx = threadIdx.x;
-    const size_t block_offset = (size_t) bidx * p.elts_per_block + (size_t) tidx * NUM_ELTS;
-    const size_t block_start = p.rank_offset + block_offset;
-    multi_gpu_barrier(p.barrier_in, p.barrier_flag, p.rank, RANKS, tidx, bidx, p.timeout_flag);
-    uint8_t* src[RANKS];
-    int dst_rank[RANKS];
-#pragma unroll
-    for (int ii = 0; ii < RANKS; ++ii)
-    {
-        dst_rank[ii] = (p.rank + ii) % RANKS;
-        src[ii] = p.comm[dst_rank[ii]];
-    }
-    // reduce-scatter: this rank's slice, summed into its own buffer
-    const size_t seg_end = min(p.rank_offset + (size_t) (bidx + 1) * p.elts_per_block, p.rank_offset + p.elts_per_rank);
-    for (size_t off = block_start; off < seg_end; off += (size_t) blockDim.x * NUM_ELTS)
-    {
-        uint4 vals[RANKS];
-#pragma unroll
-        for (int ii = 0; ii < RANKS; ++ii)
-            vals[ii] = *reinterpret_cast<const uint4*>(src[ii] + off * ES);
-        uint4 sums = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int ii = 0; ii < RANKS; ++ii)
-            sums = add_pack<T>(sums, vals[ii]);
-        *reinterpret_cast<uint4*>(src[0] + off * ES) = sums;
-    }
-    __syncthreads();
-    // barrier among the blocks of the same index (release / acquire): flags [RANKS + bidx * RANKS + rank]
-    if (tidx < RANKS)
-    {
-        const uint32_t flag_block_offset = RANKS + bidx * RANKS;
-        __threadfence_system();
-        st_flag_release(p.barrier_flag, p.barrier_in[tidx] + flag_block_offset + p.rank);
-        if (!wait_flag<true>(p.barrier_in[p.rank] + flag_block_offset + tidx, p.barrier_flag) && p.timeout_flag)
-            *p.timeout_flag = 1;
-    }
-    __syncthreads();
-    // all-gather: every rank's reduced slice
-    const size_t max_block_offset = min((size_t) (bidx + 1) * p.elts_per_block, p.elts_per_rank);
-    for (size_t off = block_offset; off < max_block_offset; off += (size_t) blockDim.x * NUM_ELTS)
-    {
-#pragma unroll
-        for (int ii = 0; ii < RANKS; ++ii)
-        {
-            const size_t offset_rank = (size_t) dst_rank[ii] * p.elts_per_rank + off;
-            if (offset_rank >= p.elts_total)
-                continue;
-            // the slice was written by a peer during this launch: read it past the caches
-            const ar_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ar_u32x4*>(src[ii] + offset_rank * ES));
-            *reinterpret_cast<ar_u32x4*>(p.out + offset_rank * ES) = v;
-        }
+        flag_store(p.barrier_out[tid] + p.rank, p.flag);
+        if (!flag_wait(p.barrier_out[p.rank] + tid, p.flag, p.timeout_ticks) && p.timeout_flag)
+            __hip_atomic_store(p.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -215,77 +266,9 @@ size_t div_up(size_t a, size_t b)
     return (a + b - 1) / b;
 }
 
-// kernelLaunchConfig, :295-352 (WARP_SIZE -> the 64-lane wave)
-void launch_config(int strat, mi355q_allreduce_params& param, size_t elts_per_thread, int& blocks, int& threads)
+size_t round_up(size_t a, size_t b)
 {
-    MQ_CHECK(param.elts_total % elts_per_thread == 0, "elts_total %zu must be a multiple of %zu", param.elts_total,
-        elts_per_thread);
-    blocks = 1;
-    threads = AR_BLOCK_SIZE;
-    if (strat == MI355Q_AR_ONESHOT)
-    {
-        const size_t total_threads = param.elts_total / elts_per_thread;
-        if (total_threads <= AR_BLOCK_SIZE)
-        {
-            threads = (int) (AR_WAVE * div_up(total_threads, AR_WAVE));
-            blocks = 1;
-        }
-        else
-        {
-            threads = AR_BLOCK_SIZE;
-            blocks = (int) std::min<size_t>(AR_MAX_BLOCKS, div_up(total_threads, AR_BLOCK_SIZE));
-        }
-        param.elts_per_rank = param.elts_total;
-        param.elts_per_block = elts_per_thread * div_up(param.elts_per_rank, elts_per_thread * blocks);
-        param.rank_offset = 0;
-    }
-    else
-    {
-        MQ_CHECK(param.elts_total % param.ranks_per_node == 0, "elts_total %zu not divisible by %zu ranks",
-            param.elts_total, param.ranks_per_node);
-        const size_t elts_per_rank = param.elts_total / param.ranks_per_node;
-        MQ_CHECK(elts_per_rank % elts_per_thread == 0, "elts_per_rank %zu must be a multiple of %zu", elts_per_rank,
-            elts_per_thread);
-        size_t total_threads = elts_per_rank / elts_per_thread;
-        total_threads = AR_WAVE * div_up(total_threads, AR_WAVE);
-        size_t b = 1;
-        while (total_threads % b != 0 || total_threads / b > AR_BLOCK_SIZE)
-            b += 1;
-        threads = (int) (total_threads / b);
-        if (b > AR_MAX_BLOCKS)
-        {
-            size_t iter_factor = 1;
-            while (b / iter_factor > AR_MAX_BLOCKS || b % iter_factor)
-                iter_factor += 1;
-            b /= iter_factor;
-        }
-        blocks = (int) b;
-        param.elts_per_rank = elts_per_rank;
-        param.elts_per_block = param.elts_per_rank / blocks;
-        param.elts_per_block = elts_per_thread * div_up(param.elts_per_block, elts_per_thread);
-        param.rank_offset = param.rank * param.elts_per_rank;
-    }
-}
-
-ArArgs to_args(const mi355q_allreduce_params& q)
-{
-    ArArgs a{};
-    a.elts_total = q.elts_total;
-    a.elts_per_rank = q.elts_per_rank;
-    a.elts_per_block = q.elts_per_block;
-    a.rank_offset = q.rank_offset;
-    a.ranks = (int) q.ranks_per_node;
-    a.rank = (int) q.local_rank;
-    a.barrier_flag = q.barrier_flag;
-    for (size_t i = 0; i < q.ranks_per_node; ++i)
-    {
-        a.barrier_in[i] = q.peer_barrier_ptrs_in[i];
-        a.barrier_out[i] = q.peer_barrier_ptrs_out[i];
-        a.comm[i] = static_cast<uint8_t*>(q.peer_comm_buffer_ptrs[i]);
-    }
-    a.out = static_cast<uint8_t*>(q.local_output_buffer_ptr);
-    a.timeout_flag = q.timeout_flag;
-    return a;
+    return div_up(a, b) * b;
 }
 
 void check_params(const mi355q_allreduce_params& q)
@@ -296,30 +279,80 @@ void check_params(const mi355q_allreduce_params& q)
         MQ_CHECK(q.peer_barrier_ptrs_in[i] && q.peer_barrier_ptrs_out[i] && q.peer_comm_buffer_ptrs[i], "null peer pointer %zu", i);
 }
 
-template <typename T, int RANKS>
-void dispatch_kernels(int strat, const ArArgs& a, int blocks, int threads, hipStream_t stream)
+ArArgs to_args(const mi355q_allreduce_params& q)
 {
-    if (strat == MI355Q_AR_ONESHOT)
-        hipLaunchKernelGGL((one_shot_kernel<T, RANKS>), dim3(blocks), dim3(threads), 0, stream, a);
-    else
-        hipLaunchKernelGGL((two_shot_kernel<T, RANKS>), dim3(blocks), dim3(threads), 0, stream, a);
+    ArArgs a{};
+    a.ranks = (int) q.ranks_per_node;
+    a.rank = (int) q.local_rank;
+    a.flag = q.barrier_flag;
+    for (size_t i = 0; i < q.ranks_per_node; ++i)
+    {
+        a.barrier_in[i] = q.peer_barrier_ptrs_in[i];
+        a.barrier_out[i] = q.peer_barrier_ptrs_out[i];
+        a.comm[i] = static_cast<uint8_t*>(q.peer_comm_buffer_ptrs[i]);
+    }
+    a.out = static_cast<uint8_t*>(q.local_output_buffer_ptr);
+    a.timeout_flag = q.timeout_flag;
+    a.timeout_ticks = (uint64_t) (q.timeout_ms ? q.timeout_ms : 2000u) * 100000ull; // 100 MHz
+    return a;
 }
 
 template <typename T>
 void invoke(mi355q_allreduce_params& q, int strat, hipStream_t stream)
 {
-    const size_t elts_per_thread = 16 / ArElem<T>::SIZE;
-    int blocks, threads;
-    launch_config(strat, q, elts_per_thread, blocks, threads);
-    const ArArgs a = to_args(q);
-    switch (q.ranks_per_node)
+    const size_t es = sizeof(T) == 4 ? 4 : 2;
+    const size_t total = q.elts_total * es;
+    const size_t ranks = q.ranks_per_node;
+    const size_t comm_bytes = q.comm_buffer_bytes ? q.comm_buffer_bytes : mi355q_allreduce_max_workspace_size((int) ranks);
+    ArArgs a = to_args(q);
+    a.total_bytes = total;
+    // the caller's contract (allreducePlugin.cpp:195-199) is "input already in my comm buffer"; with local_input_buffer_ptr
+    // the kernel reads the input where it lies instead.  The staged copy sits at the start of the own buffer, which is
+    // scatter slot / one-shot slot 0: for rank != 0 another rank overwrites it, so it is read from a private copy only
+    // when it IS the input -- hence the requirement below.
+    MQ_CHECK(q.local_input_buffer_ptr, "local_input_buffer_ptr: the push kernels read the input where it lies");
+    a.in = static_cast<const uint8_t*>(q.local_input_buffer_ptr);
+    MQ_CHECK(((uintptr_t) a.in & 15) == 0 && ((uintptr_t) a.out & 15) == 0, "input / output must be 16-byte aligned");
+    int blocks;
+    if (strat == MI355Q_AR_ONESHOT)
     {
-    case 2: dispatch_kernels<T, 2>(strat, a, blocks, threads, stream); break;
-    case 4: dispatch_kernels<T, 4>(strat, a, blocks, threads, stream); break;
-    case 6: dispatch_kernels<T, 6>(strat, a, blocks, threads, stream); break;
-    case 8: dispatch_kernels<T, 8>(strat, a, blocks, threads, stream); break;
-    default: MQ_CHECK(false, "customAllReduce: ranks_per_node %zu (2, 4, 6, 8)", q.ranks_per_node);
+        MQ_CHECK(total % 16 == 0, "elts_total %zu must be a multiple of %zu", q.elts_total, 16 / es);
+        a.slot_bytes = round_up(total, 256);
+        MQ_CHECK(ranks * a.slot_bytes <= comm_bytes, "one-shot all-reduce of %zu bytes x %zu ranks exceeds the %zu-byte comm buffer",
+            total, ranks, comm_bytes);
+        blocks = (int) std::min<size_t>(AR_MAX_WGS, std::max<size_t>(1, div_up(total, AR_MIN_CHUNK)));
+        a.chunk_bytes = round_up(div_up(total, blocks), 16);
+        q.elts_per_rank = q.elts_total;
+        q.rank_offset = 0;
     }
+    else
+    {
+        MQ_CHECK(q.elts_total % ranks == 0, "elts_total %zu not divisible by %zu ranks", q.elts_total, ranks);
+        const size_t slice = total / ranks;
+        MQ_CHECK(slice % 16 == 0, "elts_per_rank %zu must be a multiple of %zu", q.elts_total / ranks, 16 / es);
+        MQ_CHECK(2 * total <= comm_bytes, "two-shot all-reduce of %zu bytes needs a %zu-byte comm buffer, have %zu", total,
+            2 * total, comm_bytes);
+        a.slot_bytes = slice;
+        blocks = (int) std::min<size_t>(AR_MAX_WGS, std::max<size_t>(1, div_up(slice, AR_MIN_CHUNK)));
+        a.chunk_bytes = round_up(div_up(slice, blocks), 16);
+        q.elts_per_rank = q.elts_total / ranks;
+        q.rank_offset = q.local_rank * q.elts_per_rank;
+    }
+    q.elts_per_block = a.chunk_bytes / es;
+#define MQ_AR_LAUNCH(R)                                                                                                \
+    if (strat == MI355Q_AR_ONESHOT)                                                                                    \
+        hipLaunchKernelGGL((one_shot_push_kernel<T, R>), dim3(blocks), dim3(AR_THREADS), 0, stream, a);                \
+    else                                                                                                               \
+        hipLaunchKernelGGL((two_shot_push_kernel<T, R>), dim3(blocks), dim3(AR_THREADS), 0, stream, a)
+    switch (ranks)
+    {
+    case 2: MQ_AR_LAUNCH(2); break;
+    case 4: MQ_AR_LAUNCH(4); break;
+    case 6: MQ_AR_LAUNCH(6); break;
+    case 8: MQ_AR_LAUNCH(8); break;
+    default: MQ_CHECK(false, "customAllReduce: ranks_per_node %zu (2, 4, 6, 8)", ranks);
+    }
+#undef MQ_AR_LAUNCH
     MQ_HIP(hipGetLastError());
 }
 
@@ -332,8 +365,7 @@ void allreduce_params_deserialize(
     MQ_CHECK(buffer_ptrs, "null workspace");
     MQ_CHECK(tpSize >= 2 && tpSize <= MI355Q_MAX_RANKS_PER_NODE && tpRank < tpSize, "tpSize %zu tpRank %zu", tpSize, tpRank);
     out = mi355q_allreduce_params{};
-    // even calls use the ping buffers, odd ones the pong buffers: no need to wait for the peers to be done with the
-    // previous call before the input is copied in
+    // even calls use the ping buffers, odd ones the pong buffers (header comment)
     const size_t buffer_offset = (flag_value % 2 == 0) ? 0 : tpSize;
     for (size_t i = 0; i < tpSize; ++i)
     {
@@ -370,8 +402,22 @@ void custom_all_reduce(mi355q_allreduce_params& params, void* data, size_t elts,
 void multi_gpu_barrier_launch(const mi355q_allreduce_params& params, hipStream_t stream)
 {
     check_params(params);
-    hipLaunchKernelGGL(multi_gpu_barrier_kernel, dim3(1), dim3(AR_WAVE), 0, stream, to_args(params));
+    hipLaunchKernelGGL(multi_gpu_barrier_kernel, dim3(1), dim3(64), 0, stream, to_args(params));
     MQ_HIP(hipGetLastError());
+}
+
+// a host-visible word the kernels set when a wait runs out of time (one per process; read it from the host at will)
+void allreduce_alloc_timeout_flag(uint32_t** flag)
+{
+    MQ_CHECK(flag, "null argument");
+    void* p = nullptr;
+    MQ_HIP(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(p, 0, 64);
+    *flag = static_cast<uint32_t*>(p);
+}
+void allreduce_free_timeout_flag(uint32_t* flag)
+{
+    MQ_HIP(hipHostFree(flag));
 }
 
 // ---- IpcMemory (tensorrt_llm/_ipc_utils.py:66-133, cpp/tensorrt_llm/runtime/ipcUtils.cpp)

@@ -77,6 +77,8 @@ void allreduce_params_deserialize(
     mi355q_allreduce_params& out, const void* const* buffer_ptrs, size_t tpSize, size_t tpRank, uint32_t flag_value);
 void custom_all_reduce(mi355q_allreduce_params& params, void* data, size_t elts, int dtype, int strat, hipStream_t stream);
 void multi_gpu_barrier_launch(const mi355q_allreduce_params& params, hipStream_t stream);
+void allreduce_alloc_timeout_flag(uint32_t** flag);
+void allreduce_free_timeout_flag(uint32_t* flag);
 void ipc_alloc(size_t bytes, void** ptr);
 void ipc_free(void* ptr);
 void ipc_get_handle(void* ptr, uint8_t* handle);

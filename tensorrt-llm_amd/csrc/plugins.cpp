@@ -695,15 +695,17 @@ struct AllReducePlugin : PluginBase
         const int64_t size = dims_prod(inDesc[0].dims, 0, inDesc[0].dims.nbDims);
         const size_t sizePerElem = dtype_size(mType);
         int runtimeStrategy = mStrategy;
-        if (runtimeStrategy == MI355Q_AR_AUTO)
-            runtimeStrategy = mi355q_allreduce_select_implementation(
-                size * sizePerElem, (int) mGroup.size(), mi355q_allreduce_max_workspace_size((int) mGroup.size()));
         if (runtimeStrategy == MI355Q_AR_RING)
             MQ_UNSUPPORTED(
                 "AllReduce: the RING strategy is RCCL's all-reduce, issued by the host side (torch.distributed, "
                 "mi355q/tp.py all_reduce_sum); this plugin runs ONESHOT / TWOSHOT");
-        const int nRanks = inDesc[1].dims.d[0] / 4; // NUM_POINTERS_PER_RANK
-        MQ_CHECK(nRanks >= 2 && inDesc[1].dims.d[0] == 4 * nRanks, "all_reduce_workspace length %d", inDesc[1].dims.d[0]);
+        // the workspace table: 4 pointers per rank (NUM_POINTERS_PER_RANK), optionally followed by two more entries this
+        // library's CustomAllReduceHelper appends: the byte size of a comm buffer and the host-visible timeout word
+        const int len = inDesc[1].dims.d[0];
+        const int nRanks = (int) mGroup.size();
+        MQ_CHECK(nRanks >= 2 && (len == 4 * nRanks || len == 4 * nRanks + 2), "all_reduce_workspace length %d for %d ranks",
+            len, nRanks);
+        const int64_t* table = static_cast<const int64_t*>(inputs[1]);
         int myRank = mRank;
         if (myRank < 0)
         {
@@ -714,8 +716,21 @@ struct AllReducePlugin : PluginBase
         myRank %= nRanks;
         mi355q_allreduce_params params;
         allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, mCounter);
-        MQ_HIP(hipMemcpyAsync(
-            params.peer_comm_buffer_ptrs[myRank], inputs[0], size * sizePerElem, hipMemcpyDeviceToDevice, stream));
+        params.local_input_buffer_ptr = inputs[0]; // pushed to the peers by the kernel: no staging copy (allreducePlugin.cpp:195-199)
+        params.comm_buffer_bytes = mi355q_allreduce_max_workspace_size(nRanks);
+        if (len == 4 * nRanks + 2)
+        {
+            params.comm_buffer_bytes = (size_t) table[4 * nRanks];
+            params.timeout_flag = reinterpret_cast<uint32_t*>(table[4 * nRanks + 1]);
+            if (params.timeout_flag)
+                MQ_CHECK(*static_cast<volatile uint32_t*>(params.timeout_flag) == 0,
+                    "AllReduce: an earlier all-reduce timed out waiting for a peer rank (its output was poisoned with NaN)");
+        }
+        if (mStrategy == MI355Q_AR_AUTO) // selectImplementation, :111-139, for the real buffer size
+            runtimeStrategy = mi355q_allreduce_select_implementation(size * sizePerElem, nRanks, params.comm_buffer_bytes);
+        if (runtimeStrategy == MI355Q_AR_RING)
+            MQ_UNSUPPORTED("AllReduce: a message of %lld bytes does not fit the %zu-byte comm buffers: RING (RCCL) is the "
+                           "host side's call (mi355q/tp.py all_reduce_sum)", (long long) (size * sizePerElem), params.comm_buffer_bytes);
         custom_all_reduce(params, outputs[0], size, mType, runtimeStrategy, stream);
     }
     size_t serializationSize() const override // :268-284
@@ -1758,6 +1773,21 @@ extern "C"
             });
     }
 
+    size_t mi355q_allreduce_barrier_bytes(void)
+    {
+        return (size_t) 2 * MI355Q_MAX_RANKS_PER_NODE * MI355Q_AR_MAX_WORKGROUPS * sizeof(uint32_t);
+    }
+
+    mi355q_status mi355q_allreduce_alloc_timeout_flag(uint32_t** flag)
+    {
+        return guarded([&] { allreduce_alloc_timeout_flag(flag); });
+    }
+
+    mi355q_status mi355q_allreduce_free_timeout_flag(uint32_t* flag)
+    {
+        return guarded([&] { allreduce_free_timeout_flag(flag); });
+    }
+
     mi355q_status mi355q_multi_gpu_barrier(const mi355q_allreduce_params* params, void* stream)
     {
         return guarded(
@@ -1802,8 +1832,12 @@ extern "C"
     // AllreducePlugin::selectImplementation, plugins/ncclPlugin/allreducePlugin.cpp:111-139
     int32_t mi355q_allreduce_select_implementation(size_t messageBytes, int32_t worldSize, size_t maxWorkspaceBytes)
     {
-        if (messageBytes > maxWorkspaceBytes)
+        // the reference keeps the custom kernels up to the workspace size; the pushed two-shot here needs a scatter and
+        // a gather area (2 x message) and one-shot a slot per rank, so the crossover to RING (RCCL) comes earlier
+        if (2 * messageBytes > maxWorkspaceBytes)
             return MI355Q_AR_RING;
+        if ((size_t) worldSize * ((messageBytes + 255) / 256 * 256) > maxWorkspaceBytes)
+            return MI355Q_AR_TWOSHOT;
         if (worldSize <= 2)
             return MI355Q_AR_ONESHOT;
         if (worldSize <= 4)

@@ -109,6 +109,7 @@ class AllReduceParams(C.Structure):
         ("peer_barrier_ptrs_out", C.c_void_p * MAX_RANKS_PER_NODE),
         ("peer_comm_buffer_ptrs", C.c_void_p * MAX_RANKS_PER_NODE),
         ("local_output_buffer_ptr", C.c_void_p), ("timeout_flag", C.c_void_p),
+        ("local_input_buffer_ptr", C.c_void_p), ("comm_buffer_bytes", C.c_size_t), ("timeout_ms", C.c_uint32),
     ]
 
 
@@ -177,6 +178,9 @@ SYMBOLS = {
     "mi355q_allreduce_params_deserialize": (_i32, [C.POINTER(AllReduceParams), _PP, _sz, _sz, C.c_uint32]),
     "mi355q_custom_all_reduce": (_i32, [C.POINTER(AllReduceParams), _vp, _sz, _i32, _i32, _vp]),
     "mi355q_multi_gpu_barrier": (_i32, [C.POINTER(AllReduceParams), _vp]),
+    "mi355q_allreduce_barrier_bytes": (_sz, []),
+    "mi355q_allreduce_alloc_timeout_flag": (_i32, [_PP]),
+    "mi355q_allreduce_free_timeout_flag": (_i32, [_vp]),
     "mi355q_ipc_alloc": (_i32, [_sz, _PP]),
     "mi355q_ipc_free": (_i32, [_vp]),
     "mi355q_ipc_get_handle": (_i32, [_vp, _vp]),

@@ -15,7 +15,10 @@ from .plugin import Plugin, torch_dtype_to_trt, current_stream_ptr
 class IpcMemory:
     """A zeroed device buffer on every rank of `group`, mapped into every other rank (_ipc_utils.py:66-133)."""
 
-    IPC_BARRIERS_SIZE_PER_GPU = 25 * 4  # (MAX_ALL_REDUCE_BLOCKS + 1) * sizeof(uint32)
+    @staticmethod
+    def barrier_bytes():
+        """One barrier-flag array per rank: flags per (phase, source rank, workgroup) (replaces IPC_BARRIERS_SIZE_PER_GPU)."""
+        return L.lib().mi355q_allreduce_barrier_bytes()
 
     def __init__(self, size, group=None):
         self.group = group
@@ -63,42 +66,72 @@ class CustomAllReduceHelper:
     def max_workspace_size_auto(tp_size):
         return L.lib().mi355q_allreduce_max_workspace_size(tp_size)
 
-    def __init__(self, size=None, group=None):
+    def __init__(self, size=None, group=None, timeout_ms=0):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         size = size or self.max_workspace_size_auto(self.world)
         self.size = size
+        self.timeout_ms = timeout_ms
         self.buffers = [IpcMemory(size, group), IpcMemory(size, group),
-                        IpcMemory(IpcMemory.IPC_BARRIERS_SIZE_PER_GPU * self.world, group),
-                        IpcMemory(IpcMemory.IPC_BARRIERS_SIZE_PER_GPU * self.world, group)]
+                        IpcMemory(IpcMemory.barrier_bytes(), group), IpcMemory(IpcMemory.barrier_bytes(), group)]
+        flag = C.c_void_p()
+        L.check(L.lib().mi355q_allreduce_alloc_timeout_flag(C.byref(flag)))
+        self._timeout_flag = flag.value                      # host-visible word the kernels set when a peer never arrives
         ptrs = []
         for b in self.buffers:
             ptrs += b.serialize()
-        self.workspace = torch.tensor(ptrs, dtype=torch.int64, device="cpu")
+        # the reference's table (4 pointers per rank) + the comm-buffer byte size + the timeout word
+        self.workspace = torch.tensor(ptrs + [size, self._timeout_flag], dtype=torch.int64, device="cpu")
         self.counter = 0
-        self._plugins = {}
+
+    def timed_out(self):
+        return C.cast(self._timeout_flag, C.POINTER(C.c_uint32))[0] != 0
 
     def close(self):
+        timed_out = self.timed_out()
         for b in self.buffers:
             b.close()
+        L.lib().mi355q_allreduce_free_timeout_flag(self._timeout_flag)
+        if timed_out:
+            raise RuntimeError("custom all-reduce: a wait for a peer rank timed out during this session")
 
-    def allreduce(self, tensor, strategy=L.AR_AUTO):
+    def _params(self, tensor, out):
+        """AllReduceParams for the direct launcher (mi355q_custom_all_reduce), same state as the plugin path."""
+        p = L.AllReduceParams()
+        table = (C.c_void_p * (4 * self.world))(*[int(v) for v in self.workspace[:4 * self.world]])
+        L.check(L.lib().mi355q_allreduce_params_deserialize(C.byref(p), table, self.world, self.rank, self.counter))
+        p.local_input_buffer_ptr = tensor.data_ptr()
+        p.comm_buffer_bytes = self.size
+        p.timeout_flag = self._timeout_flag
+        p.timeout_ms = self.timeout_ms
+        return p
+
+    def allreduce(self, tensor, strategy=L.AR_AUTO, out=None, direct=False):
         """functional.py `allreduce(tensor, group, workspace, strategy)`: RING -> RCCL (torch.distributed), else the
-        AllReduce plugin (one-shot / two-shot).  Every call advances the barrier flag / ping-pong counter."""
+        AllReduce plugin (one-shot / two-shot; `direct`: the launcher below the plugin, which also takes `timeout_ms`).
+        Every call advances the barrier flag / ping-pong counter."""
         nbytes = tensor.numel() * tensor.element_size()
         strat = strategy
         if strat == L.AR_AUTO:
             strat = L.lib().mi355q_allreduce_select_implementation(nbytes, self.world, self.size)
-        if strat == L.AR_RING or nbytes > self.size:
-            out = tensor.clone()
+        if strat == L.AR_RING:
+            out = tensor.clone() if out is None else out.copy_(tensor)
             dist.all_reduce(out, group=self.group)
             return out
         self.counter += 1
+        tensor = tensor.contiguous()
+        out = torch.empty_like(tensor) if out is None else out
+        if direct:
+            if self.timed_out():
+                raise RuntimeError("custom all-reduce: an earlier all-reduce timed out waiting for a peer rank")
+            p = self._params(tensor, out)
+            L.check(L.lib().mi355q_custom_all_reduce(C.byref(p), out.data_ptr(), tensor.numel(),
+                                                     torch_dtype_to_trt(tensor.dtype), strat, current_stream_ptr()))
+            return out
         plg = Plugin("AllReduce", [("group", list(range(self.world)), L.FIELD_INT32),
                                    ("type_id", torch_dtype_to_trt(tensor.dtype), L.FIELD_INT32),
                                    ("strategy", strat, L.FIELD_INT8), ("counter", self.counter, L.FIELD_INT32),
                                    ("rank", self.rank, L.FIELD_INT32)])
-        out = torch.empty_like(tensor)
-        plg.enqueue([tensor.contiguous(), self.workspace], [out])
+        plg.enqueue([tensor, self.workspace], [out])
         return out

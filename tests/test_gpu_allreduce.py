@@ -1,7 +1,8 @@
-"""GPU parity: the custom one-shot / two-shot all-reduce (row a16) through the AllReduce plugin, with the ranks as
-separate PROCESSES that map each other's buffers through HIP IPC.  The box has one GPU, so all ranks sit on device 0:
-this exercises the kernels' indexing, flag protocol, ping-pong buffers and T-arithmetic summation order bit for bit
-against the oracle, but NOT the cross-GPU (xGMI) visibility of the flags -- DESIGN.md says so."""
+"""GPU parity: the custom one-shot / two-shot all-reduce (row a16) through the AllReduce plugin and the launcher below
+it, with the ranks as separate PROCESSES that map each other's buffers through HIP IPC.  The box has one GPU, so all
+ranks sit on device 0: this exercises the kernels' indexing, per-workgroup flag protocol, ping-pong buffers, the
+T-arithmetic summation order bit for bit against the oracle, and the bounded wait (a late rank -> NaN output + the
+host-visible timeout word), but NOT the cross-GPU (xGMI) visibility of the flags -- DESIGN.md says so."""
 import os
 import sys
 
@@ -28,19 +29,24 @@ def _worker(rank, world, port, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok, msg = True, ""
     try:
-        helper = CustomAllReduceHelper(size=1 << 20)
+        helper = CustomAllReduceHelper(size=8 << 20)
+        # the last two: 1 MiB (256 workgroups of 4 KiB, the cfg4 M = 64 message) and 2 MiB per rank
         cases = [(torch.float16, 8 * 64), (torch.float16, 8 * 1024 * 3), (torch.bfloat16, 8192 * 4),
-                 (torch.float32, 4 * 1024 * 5), (torch.float16, 8 * world * 999), (torch.bfloat16, 64 * world)]
+                 (torch.float32, 4 * 1024 * 5), (torch.float16, 8 * world * 999), (torch.bfloat16, 64 * world),
+                 (torch.bfloat16, 64 * 8192), (torch.float16, 1 << 20)]
         for strat, sname in ((L.AR_ONESHOT, "oneshot"), (L.AR_TWOSHOT, "twoshot")):
-            for dtype, n in cases:
+            for ci, (dtype, n) in enumerate(cases):
                 g = torch.Generator().manual_seed(1234 + n)
                 inputs = [(torch.randn(n, generator=g) * 3).to(dtype) for _ in range(world)]  # every rank builds all
-                out = helper.allreduce(inputs[rank].to(dev), strategy=strat)
+                x = inputs[rank].to(dev)
+                # alternate: plugin / direct launcher, out of place / in place
+                out = helper.allreduce(x, strategy=strat, direct=bool(ci & 1), out=x if ci & 2 else None)
                 torch.cuda.synchronize()
                 ref = oracle.custom_all_reduce(inputs, rank, sname)
                 if not torch.equal(out.cpu().view(torch.uint8), ref.view(torch.uint8)):
                     d = (out.cpu().float() - ref.float()).abs().max().item()
-                    ok, msg = False, f"rank {rank} {sname} {dtype} n={n}: max abs diff {d}"
+                    ok, msg = False, (f"rank {rank} {sname} {dtype} n={n}: max abs diff {d}; out {out[:4].tolist()} ref "
+                                     f"{ref[:4].tolist()} inputs {[t[:4].tolist() for t in inputs]}")
                     break
             if not ok:
                 break
@@ -52,6 +58,36 @@ def _worker(rank, world, port, results):
                 ok, msg = False, f"rank {rank} AUTO small: {y[:4].tolist()}"
         dist.barrier()
         helper.close()
+        if ok and world == 2:
+            # a late rank: rank 1 arrives 1.5 s after rank 0, whose waits are bounded to 0.3 s -> rank 0 gets NaN and
+            # the timeout word, and refuses further all-reduces; rank 1 finds rank 0's data and flags in place
+            late = CustomAllReduceHelper(size=1 << 20, timeout_ms=300 if rank == 0 else 0)
+            x = torch.full((4096,), float(rank + 1), dtype=torch.float16, device=dev)
+            dist.barrier()
+            if rank == 1:
+                import time
+                time.sleep(1.5)
+            y = late.allreduce(x, strategy=L.AR_ONESHOT, direct=True)
+            torch.cuda.synchronize()
+            if rank == 0:
+                if not (torch.isnan(y).all().item() and late.timed_out()):
+                    ok, msg = False, f"rank 0: expected NaN output and the timeout word, got {y[:4].tolist()} / {late.timed_out()}"
+                try:
+                    late.allreduce(x, strategy=L.AR_ONESHOT)
+                    ok, msg = False, "rank 0: the plugin accepted work after a timeout"
+                except Exception as e:  # noqa: BLE001
+                    if "timed out" not in str(e):
+                        ok, msg = False, f"rank 0: unexpected error {e}"
+            elif not torch.equal(y.cpu(), torch.full((4096,), 3.0, dtype=torch.float16)) or late.timed_out():
+                ok, msg = False, f"rank 1: {y[:4].tolist()} timed_out={late.timed_out()}"
+            dist.barrier()
+            try:
+                late.close()
+                if rank == 0:
+                    ok, msg = False, "rank 0: close() did not report the timeout"
+            except RuntimeError as e:
+                if rank != 0 or "timed out" not in str(e):
+                    ok, msg = False, f"rank {rank}: close raised {e}"
     except Exception as e:  # noqa: BLE001 -- report through the queue, the parent asserts
         ok, msg = False, f"rank {rank}: {type(e).__name__}: {e}"
     results.put((rank, ok, msg))
