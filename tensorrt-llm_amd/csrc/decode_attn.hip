@@ -17,6 +17,7 @@
 #include "decode_common.h"
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 namespace mi355q
@@ -305,76 +306,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
         }
     }
     __syncthreads();
-    for (int i = tid; i < G * DH; i += NW * 64)
-    {
-        const int g = i / DH, d = i % DH;
-        float mm = NEG_BIG;
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-            mm = fmaxf(mm, red[(w * G + g) * (DH + 2) + DH]);
-        float ll = 0.f, o = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-        {
-            const float* r = red + (w * G + g) * (DH + 2);
-            const float c = __builtin_amdgcn_exp2f(r[DH] - mm);
-            ll += r[DH + 1] * c;
-            o += r[d] * c;
-        }
-        const int h = hk * G + g;
-        if (p.splits == 1)
-        {
-            // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2285-2290)
-            const float r = o / (ll + 1e-6f);
-            reinterpret_cast<uint16_t*>(p.out)[((size_t) b * Hq + h) * DH + d] = T16<T>::from_float(r);
-        }
-        else
-        {
-            const size_t pi = ((size_t) b * Hq + h) * p.splits + split;
-            p.part_acc[pi * DH + d] = o;
-            if (d == 0)
-            {
-                p.part_ml[pi * 2] = mm;
-                p.part_ml[pi * 2 + 1] = ll;
-            }
-        }
-    }
-}
-
-// multi-block merge (reference: decoderMaskedMultiheadAttentionTemplate.h:2634-2786, but partials
-// stay fp32 here).  grid = B*Hq, block = DH (64 or 128 threads).
-template <typename T>
-__global__ void decode_attn_merge_kernel(
-    const float* part_acc, const float* part_ml, void* out, int splits, int dh)
-{
-    // splits <= 64: the (m, l) pairs are fetched once, in parallel, and the rescale factors shared through LDS
-    __shared__ float c_s[64];
-    __shared__ float ll_s;
-    const size_t bh = blockIdx.x;
-    const int d = threadIdx.x;
-    if (d < 64)
-    {
-        const float m = d < splits ? part_ml[(bh * splits + d) * 2] : NEG_BIG;
-        const float l = d < splits ? part_ml[(bh * splits + d) * 2 + 1] : 0.f;
-        float mm = m;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-            mm = fmaxf(mm, __shfl_xor(mm, o));
-        const float c = __builtin_amdgcn_exp2f(m - mm);
-        float ll = l * c;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-            ll += __shfl_xor(ll, o);
-        c_s[d] = c;
-        if (d == 0)
-            ll_s = ll;
-    }
-    __syncthreads();
-    float o = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < splits; ++s)
-        o += part_acc[(bh * splits + s) * dh + d] * c_s[s];
-    reinterpret_cast<uint16_t*>(out)[bh * dh + d] = T16<T>::from_float(o / (ll_s + 1e-6f));
+    finish_states<T, G, DH, NW * 64, NW>(p, b, hk, split, red);
 }
 
 int ilog2(int x)
@@ -424,9 +356,6 @@ void launch(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStr
 {
     const int grid = q.batch * q.num_kv_heads * a.splits;
     hipLaunchKernelGGL((decode_attn_kernel<T, KVT, DH, G, U>), dim3(grid), dim3(NW * 64), 0, stream, a);
-    if (a.splits > 1)
-        hipLaunchKernelGGL((decode_attn_merge_kernel<T>), dim3(q.batch * q.num_heads), dim3(DH), 0, stream,
-            a.part_acc, a.part_ml, q.out, a.splits, DH);
 }
 
 template <typename T, int KVT, int DH, int G>
@@ -517,15 +446,54 @@ Plan make_plan(const mi355q_decode_attention_params& q)
 
 } // namespace
 
+namespace
+{
+// floats of one (sequence, kv head) group: its partial records padded to a 128-byte line
+size_t group_floats(const mi355q_decode_attention_params& q, int splits)
+{
+    const size_t g = (size_t) (q.num_heads / q.num_kv_heads);
+    return ((size_t) splits * g * (q.head_size + PART_PAD) + 31) / 32 * 32;
+}
+// bytes of the split-KV area of one call
+size_t partials_bytes(const mi355q_decode_attention_params& q, int splits)
+{
+    return (size_t) q.batch * q.num_kv_heads * group_floats(q, splits) * sizeof(float);
+}
+} // namespace
+
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
 {
     make_plan(q);
     // batch' * splits(batch') <= 1024 / Hkv + batch' for every batch' <= batch, so this bound holds
     // for any smaller batch enqueued later (TensorRT asks once, at configure time, with max shapes)
-    size_t rows = q.multi_block_mode > 0 ? (size_t) q.batch * q.multi_block_mode
-                                         : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
-    return rows * q.num_heads * (q.head_size + 2) * sizeof(float);
+    const size_t rows = q.multi_block_mode > 0 ? (size_t) q.batch * q.multi_block_mode
+                                               : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
+    const size_t groups = (size_t) q.batch * q.num_kv_heads;
+    // records + the per-group padding to a line
+    return rows * q.num_heads * (q.head_size + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);
 }
+
+#ifdef MI355Q_LAB
+namespace
+{
+unsigned long long* g_lab_stamps = nullptr;
+unsigned long long* lab_decode_stamps()
+{
+    if (!lab_env("MI355Q_ATTN_STAMPS"))
+        return nullptr;
+    if (!g_lab_stamps)
+    {
+        MQ_HIP(hipHostMalloc((void**) &g_lab_stamps, 4096 * 16 * sizeof(unsigned long long), hipHostMallocMapped));
+        std::memset(g_lab_stamps, 0, 4096 * 16 * sizeof(unsigned long long));
+    }
+    return g_lab_stamps;
+}
+} // namespace
+extern "C" const unsigned long long* mi355q_lab_decode_stamps()
+{
+    return g_lab_stamps;
+}
+#endif
 
 void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream)
 {
@@ -564,11 +532,16 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
             q.position_embedding_type);
     if (pl.splits > 1)
     {
-        const size_t need = (size_t) q.batch * q.num_heads * pl.splits * (q.head_size + 2) * sizeof(float);
+        const size_t need = partials_bytes(q, pl.splits);
         MQ_CHECK(q.workspace && q.workspace_bytes >= need, "workspace too small: %zu < %zu", q.workspace_bytes, need);
-        a.part_acc = reinterpret_cast<float*>(q.workspace);
-        a.part_ml = a.part_acc + (size_t) q.batch * q.num_heads * pl.splits * q.head_size;
+        MQ_CHECK(((uintptr_t) q.workspace & 127) == 0, "workspace must be 128-byte aligned");
+        a.group_floats = (int) group_floats(q, pl.splits);
+        a.partials = reinterpret_cast<float*>(q.workspace);
+        a.arrivals = arrival_lines((size_t) q.batch * q.num_kv_heads);
     }
+#ifdef MI355Q_LAB
+    a.stamps = lab_decode_stamps();
+#endif
     if (pl.gqa)
     {
         if (q.act_type == MI355Q_BF16)
@@ -631,7 +604,7 @@ void masked_multihead_attention_static(const mi355q_decode_attention_params& q, 
     if (pl.splits > 1)
     {
         // what THIS call's partials take (not the max-shape bound of the workspace query)
-        const size_t need = (size_t) q.batch * q.num_heads * pl.splits * (q.head_size + 2) * sizeof(float);
+        const size_t need = partials_bytes(q, pl.splits);
         MQ_CHECK(need <= DECODE_SCRATCH_BYTES,
             "split-KV partials of this call (%zu bytes: batch %d x %d heads x %d splits) exceed the %zu-byte static scratch; "
             "use mi355q_masked_multihead_attention with a workspace",
@@ -639,7 +612,8 @@ void masked_multihead_attention_static(const mi355q_decode_attention_params& q, 
         c.workspace = decode_scratch_of_current_device();
         c.workspace_bytes = DECODE_SCRATCH_BYTES;
     }
-    // every partial the merge reads is written by this call's main kernel first: nothing has to start at zero
+    // nothing has to be cleared: every partial the merge reads is written by this call first, and the arrival words
+    // (arrival_ring.hip, not part of this scratch) put themselves back to zero
     masked_multihead_attention(c, stream);
 }
 

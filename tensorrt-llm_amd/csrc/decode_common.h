@@ -21,15 +21,37 @@ struct DecodeArgs
     const int64_t* block_ptrs;
     const float* kv_scale_orig_quant;
     const float* kv_scale_quant_orig;
-    float* part_acc; // [B, Hq, splits, DH]
-    float* part_ml;  // [B, Hq, splits, 2]
+    // split-KV (the reference's multi-block mode, decoderMaskedMultiheadAttentionTemplate.h:2614-2786): one group of
+    // records per (sequence, kv head): [splits][G][DH + 4] floats (acc | m | l | pad), group stride `group_floats` (a multiple
+    // of 32 floats: no 128-byte line is shared between groups), and one arrival word per group (arrival_ring.hip:
+    // zero at launch, ARRIVAL_WORD_STRIDE words apart)
+    float* partials;
+    uint32_t* arrivals;
+    int group_floats;
     int batch, num_heads, num_kv_heads;
     int max_blocks, tpb_log2;
     int splits;
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale;
     float score_scale; // 1 / (sqrt(Dh) * q_scaling)
+#ifdef MI355Q_LAB
+    unsigned long long* stamps; // lab: [workgroup][16] s_memrealtime stamps (100 MHz), or null
+#endif
 };
+
+#ifdef MI355Q_LAB
+#define MQ_STAMP(p, i)                                                                                                 \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if ((p).stamps && threadIdx.x == 0)                                                                            \
+            (p).stamps[(size_t) blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                            \
+    } while (0)
+#else
+#define MQ_STAMP(p, i)                                                                                                 \
+    do                                                                                                                 \
+    {                                                                                                                  \
+    } while (0)
+#endif
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
@@ -103,47 +125,95 @@ __device__ __forceinline__ uint8_t float_to_fp8(float x)
     return (uint8_t) (__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
 }
 
-// Stage q (G heads), k, v of the new token into LDS as floats already rounded to T: bias add in T,
-// RoPE in fp32 (decoderMaskedMultiheadAttentionTemplate.h:1391-1527).  smem: [(G + 2) * DH] floats
-// = q[G][DH], k[DH], v[DH].  Ends with a barrier.
+// The new token's q (G heads), k, v and their biases as loaded: 16-byte vectors, all of them issued before the first
+// use (the scalar form -- one 2-byte load per trip of a 5-trip loop, each waited for -- cost five cold HBM round trips).
+// No load sits under a branch (a missing bias re-reads qkv and is ignored): the compiler's vmcnt bookkeeping stays
+// exact, so loads the caller issues AFTER these are still in flight while the token is staged.
+template <int G, int DH>
+struct NewTokenRegs
+{
+    static constexpr int NV = (G + 2) * DH / 8; // 16-byte vectors of q (G heads), k, v
+    static constexpr int TRIPS = (NV + NW * 64 - 1) / (NW * 64);
+    uint4 x[TRIPS], bias[TRIPS];
+};
+
 template <typename T, int DH, int G>
-__device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int hk, int tl, float* smem)
+__device__ __forceinline__ void issue_new_token(const DecodeArgs& p, int b, int hk, NewTokenRegs<G, DH>& r)
 {
     const int tid = threadIdx.x;
     const int Hq = p.num_heads, Hkv = p.num_kv_heads;
-    // ---- stage q (G heads), k, v of the new token: bias add in T, RoPE in fp32, round to T
+    const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * DH;
+    const uint16_t* bias = p.qkv_bias ? reinterpret_cast<const uint16_t*>(p.qkv_bias) : qkv;
+#pragma unroll
+    for (int t = 0; t < NewTokenRegs<G, DH>::TRIPS; ++t)
     {
-        const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * DH;
-        const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.qkv_bias);
-        // 16-byte loads, all of them issued before the first use: the scalar form (one 2-byte load per trip of a
-        // 5-trip loop, each waited for) cost five cold HBM round trips -- most of a workgroup's fixed ~8 us
-        constexpr int NV = (G + 2) * DH / 8;                     // 16-byte vectors of q (G heads), k, v
-        constexpr int TRIPS = (NV + NW * 64 - 1) / (NW * 64);
-        uint4 xv[TRIPS], bv[TRIPS];
-        int offv[TRIPS];
-#pragma unroll
-        for (int t = 0; t < TRIPS; ++t)
+        const int v = min(tid + t * NW * 64, NewTokenRegs<G, DH>::NV - 1); // past the end: a valid vector, not stored
+        const int vec = (v * 8) / DH, d = (v * 8) % DH;
+        const int off = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
+        r.x[t] = *reinterpret_cast<const uint4*>(qkv + off);
+        r.bias[t] = *reinterpret_cast<const uint4*>(bias + off);
+    }
+}
+
+// base^(2 i / rot_dim) of rotary pair i = threadIdx.x: needs no sequence length unless the base is rescaled by it
+// (dynamic NTK), so a kernel computes it while its first loads are in flight (powf is a few hundred instructions).
+__device__ __forceinline__ float rope_early_pow(const DecodeArgs& p)
+{
+    const bool rope = p.pos_type == 1 || p.pos_type == 2;
+    if (!rope || p.rot_scale_type == 2 || (int) threadIdx.x >= (p.rot_dim >> 1))
+        return 1.f;
+    return powf(p.rot_base, (float) (2 * threadIdx.x) / (float) p.rot_dim);
+}
+
+// Stage q (G heads), k, v of the new token into LDS as floats already rounded to T: bias add in T,
+// RoPE in fp32 (decoderMaskedMultiheadAttentionTemplate.h:1391-1527).  smem: [(G + 2) * DH] floats
+// = q[G][DH], k[DH], v[DH].  Ends with a barrier.  The cos / sin table is built before the token's registers are
+// touched, i.e. while their loads are still in flight.
+template <typename T, int DH, int G>
+__device__ __forceinline__ void stage_new_token(
+    const DecodeArgs& p, const NewTokenRegs<G, DH>& r, int tl, float* smem, float early_pow)
+{
+    const int tid = threadIdx.x;
+    {
+        // cos / sin of the token's angles depend on the pair index only: one table per block (rot_dim / 2 entries)
+        // instead of powf + sincosf for every (head, pair) -- with 8 query heads per kv head that was 9x the
+        // transcendental work, in every split of the sequence
+        __shared__ float rope_tab[DH];
+        const bool rope = p.pos_type == 1 || p.pos_type == 2; // kROPE_GPTJ / kROPE_GPT_NEOX
+        const int half = p.rot_dim >> 1;
+        if (rope && tid < half)
         {
-            const int v = min(tid + t * NW * 64, NV - 1); // past the end: a valid vector, not stored
-            const int vec = (v * 8) / DH, d = (v * 8) % DH;
-            offv[t] = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
-            xv[t] = *reinterpret_cast<const uint4*>(qkv + offv[t]);
-            bv[t] = make_uint4(0, 0, 0, 0);
+            float scale = p.rot_scale;
+            float pw = early_pow;
+            // update_rotary_base_n_scale (decoderMaskedMultiheadAttentionUtils.h:2552-2579)
+            if (p.rot_scale_type == 2)
+            {
+                float base = p.rot_base;
+                if (tl > p.rot_max_pos)
+                {
+                    float bb = tl * (scale / p.rot_max_pos) - (scale - 1.f);
+                    base = base * powf(bb, (float) p.rot_dim / (float) (p.rot_dim - 2));
+                }
+                scale = 1.f;
+                pw = powf(base, (float) (2 * tid) / (float) p.rot_dim);
+            }
+            else if (p.rot_scale_type == 1)
+                scale = 1.f / scale;
+            const float ang = ((float) tl * scale) / pw;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            rope_tab[2 * tid] = cs;
+            rope_tab[2 * tid + 1] = sn;
         }
-        if (bias)
-        {
+        const bool bias = p.qkv_bias != nullptr;
 #pragma unroll
-            for (int t = 0; t < TRIPS; ++t)
-                bv[t] = *reinterpret_cast<const uint4*>(bias + offv[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < TRIPS; ++t)
+        for (int t = 0; t < NewTokenRegs<G, DH>::TRIPS; ++t)
         {
             const int v = tid + t * NW * 64;
-            if (v < NV)
+            if (v < NewTokenRegs<G, DH>::NV)
             {
-                const uint32_t xw[4] = {xv[t].x, xv[t].y, xv[t].z, xv[t].w};
-                const uint32_t bw[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
+                const uint32_t xw[4] = {r.x[t].x, r.x[t].y, r.x[t].z, r.x[t].w};
+                const uint32_t bw[4] = {r.bias[t].x, r.bias[t].y, r.bias[t].z, r.bias[t].w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                 {
@@ -156,33 +226,6 @@ __device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int 
                     smem[v * 8 + j] = x;
                 }
             }
-        }
-        // cos / sin of the token's angles depend on the pair index only: one table per block (rot_dim / 2 entries)
-        // instead of powf + sincosf for every (head, pair) -- with 8 query heads per kv head that was 9x the
-        // transcendental work, in every split of the sequence
-        __shared__ float rope_tab[DH];
-        const bool rope = p.pos_type == 1 || p.pos_type == 2; // kROPE_GPTJ / kROPE_GPT_NEOX
-        const int half = p.rot_dim >> 1;
-        if (rope && tid < half)
-        {
-            float base = p.rot_base, scale = p.rot_scale;
-            // update_rotary_base_n_scale (decoderMaskedMultiheadAttentionUtils.h:2552-2579)
-            if (p.rot_scale_type == 2)
-            {
-                if (tl > p.rot_max_pos)
-                {
-                    float bb = tl * (scale / p.rot_max_pos) - (scale - 1.f);
-                    base = base * powf(bb, (float) p.rot_dim / (float) (p.rot_dim - 2));
-                }
-                scale = 1.f;
-            }
-            else if (p.rot_scale_type == 1)
-                scale = 1.f / scale;
-            const float ang = ((float) tl * scale) / powf(base, (float) (2 * tid) / (float) p.rot_dim);
-            float sn, cs;
-            sincosf(ang, &sn, &cs);
-            rope_tab[2 * tid] = cs;
-            rope_tab[2 * tid + 1] = sn;
         }
         __syncthreads();
         if (rope)
@@ -200,6 +243,196 @@ __device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int 
             }
             __syncthreads();
         }
+    }
+}
+
+template <typename T, int DH, int G>
+__device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int hk, int tl, float* smem)
+{
+    NewTokenRegs<G, DH> r;
+    issue_new_token<T, DH, G>(p, b, hk, r);
+    stage_new_token<T, DH, G>(p, r, tl, smem, rope_early_pow(p));
+}
+
+typedef __attribute__((address_space(1))) uint32_t dec_gu32;
+typedef __attribute__((address_space(1))) float dec_gf32;
+typedef __attribute__((ext_vector_type(4))) float dec_f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t dec_u32x4;
+
+constexpr int PART_PAD = 4; // a partial record is [DH | m | l | 2 pad] floats: 16-byte aligned rows
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dec_rsrc(const void* p, size_t bytes)
+{
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (u >> 32));
+    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t) bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*) (((uint64_t) hi << 32) | lo), 0, nb, 0x00020000);
+}
+
+// The end of a decode workgroup: merge its NSTATES partial states (LDS `red`: [NSTATES][G][DH + 2] = acc | m | l) and
+// either write the output (no split) or take part in the split-KV merge INSIDE the launch (the reference does the same
+// with its block_counter, decoderMaskedMultiheadAttentionTemplate.h:2614-2786; a second kernel used to do it here).
+// A thread owns 4 consecutive d of one head.  Split-KV: the workgroup publishes its G merged states into its records
+// of the (sequence, kv head) group -- 16-byte write-through (sc1) stores --, every storing wave drains vmcnt, barrier,
+// ONE lane counts the workgroup on the group's arrival word, and the workgroup whose arrival completes the count
+// merges the splits in split order (deterministic) with sc1 loads, all of a thread's loads issued before the first
+// use.  Hand-off form: MI355X_MICROARCH.md, Valid forms, row "one lane of each storing workgroup ... the workgroup
+// whose add came last".  The arrival word comes from arrival_ring.hip (zero at launch, one per 128-byte line, put
+// back to zero by the last arrival's own wrapping increment -- one round trip, no reset pass, graph replay safe).
+// `red` is reused as scratch (>= 1 + G * 65 floats).
+template <typename T, int G, int DH, int THREADS, int NSTATES>
+__device__ __forceinline__ void finish_states(const DecodeArgs& p, int b, int hk, int split, float* red)
+{
+    constexpr int RS = DH + 2;           // LDS row stride
+    constexpr int REC = DH + PART_PAD;   // global record stride (floats)
+    const int tid = threadIdx.x;
+    const size_t grp_bytes = (size_t) p.group_floats * sizeof(float);
+    const __amdgpu_buffer_rsrc_t grp
+        = dec_rsrc(p.partials + ((size_t) b * p.num_kv_heads + hk) * p.group_floats, p.splits > 1 ? grp_bytes : 0);
+    for (int i = tid; i < G * DH / 4; i += THREADS)
+    {
+        const int g = i / (DH / 4), d = (i % (DH / 4)) * 4;
+        float mm = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < NSTATES; ++w)
+            mm = fmaxf(mm, red[(w * G + g) * RS + DH]);
+        float ll = 0.f;
+        dec_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NSTATES; ++w)
+        {
+            const float* r = red + (w * G + g) * RS;
+            const float c = __builtin_amdgcn_exp2f(r[DH] - mm);
+            ll += r[DH + 1] * c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] += r[d + j] * c;
+        }
+        if (p.splits == 1)
+        {
+            // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2285-2290)
+            const float inv = 1.f / (ll + 1e-6f);
+            const uint2 v = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t) b * p.num_heads + hk * G + g) * DH + d) = v;
+        }
+        else
+        {
+            const uint32_t rec = (uint32_t) ((split * G + g) * REC) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dec_u32x4, o), grp, rec + d * 4, 0, 16 /* sc1 */);
+            if (d == 0)
+            {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mm), grp, rec + DH * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ll), grp, rec + DH * 4 + 4, 0, 16);
+            }
+        }
+    }
+    if (p.splits == 1)
+        return;
+    MQ_STAMP(p, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave, before the barrier the counting lane passes
+    __syncthreads();                                 // (also: everyone is done reading `red`)
+    MQ_STAMP(p, 7);
+    int* last = reinterpret_cast<int*>(red);
+    if (tid == 0)
+    {
+        // global_atomic_inc with wrap value splits - 1: the arrival that finds splits - 1 is the last one, and its
+        // own increment puts the word back to zero for the next launch (arrival_ring.hip)
+        dec_gu32* word = (dec_gu32*) (p.arrivals + ((size_t) b * p.num_kv_heads + hk) * ARRIVAL_WORD_STRIDE);
+        const uint32_t seen = __builtin_amdgcn_atomic_inc32(word, (uint32_t) (p.splits - 1), __ATOMIC_RELAXED, "agent");
+        *last = seen == (uint32_t) (p.splits - 1);
+    }
+    __syncthreads();
+    MQ_STAMP(p, 8);
+    if (!*last)
+        return;
+    const int S = p.splits; // <= 64
+    if (S <= 8)
+    {
+        // one round trip: a thread loads the (m, l) pairs and its 4 columns of every split together
+        typedef __attribute__((ext_vector_type(2))) uint32_t dec_u32x2;
+        for (int i = tid; i < G * DH / 4; i += THREADS)
+        {
+            const int g = i / (DH / 4), d = (i % (DH / 4)) * 4;
+            dec_u32x4 v[8];
+            dec_u32x2 ml[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const uint32_t rec = (uint32_t) ((min(j, S - 1) * G + g) * REC) * 4;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(grp, rec + d * 4, 0, 16);
+                ml[j] = __builtin_amdgcn_raw_buffer_load_b64(grp, rec + DH * 4, 0, 16);
+            }
+            float mm = NEG_BIG;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                mm = fmaxf(mm, j < S ? __uint_as_float(ml[j].x) : NEG_BIG);
+            float ll = 0.f;
+            dec_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const float c = j < S ? __builtin_amdgcn_exp2f(__uint_as_float(ml[j].x) - mm) : 0.f;
+                ll = fmaf(__uint_as_float(ml[j].y), c, ll);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = fmaf(__uint_as_float(v[j][e]), c, o[e]);
+            }
+            const float inv = 1.f / (ll + 1e-6f); // decoderMaskedMultiheadAttentionTemplate.h:2771-2777
+            const uint2 w = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t) b * p.num_heads + hk * G + g) * DH + d) = w;
+        }
+        MQ_STAMP(p, 9);
+        return;
+    }
+    float* c_s = red + 1;      // [G][64] rescale factors
+    float* l_s = c_s + G * 64; // [G] merged sums
+    __syncthreads();           // everyone has read *last
+    // (m, l) of every (head, split) once: one wave per head, lane = split
+    for (int i = tid; i < G * 64; i += THREADS)
+    {
+        const int g = i >> 6, s = i & 63;
+        const uint32_t rec = (uint32_t) ((min(s, S - 1) * G + g) * REC) * 4;
+        const float m_ld = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grp, rec + DH * 4, 0, 16));
+        const float l_ld = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grp, rec + DH * 4 + 4, 0, 16));
+        const float m = s < S ? m_ld : NEG_BIG, l = s < S ? l_ld : 0.f;
+        float mm = m;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            mm = fmaxf(mm, __shfl_xor(mm, o));
+        const float c = __builtin_amdgcn_exp2f(m - mm);
+        float ll = l * c;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            ll += __shfl_xor(ll, o);
+        c_s[i] = c;
+        if (s == 0)
+            l_s[g] = ll;
+    }
+    __syncthreads();
+    for (int i = tid; i < G * DH / 4; i += THREADS)
+    {
+        const int g = i / (DH / 4), d = (i % (DH / 4)) * 4;
+        dec_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < S; s0 += 8) // 8 splits' loads in flight, summed in split order
+        {
+            dec_u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(grp, (uint32_t) ((min(s0 + j, S - 1) * G + g) * REC + d) * 4, 0, 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const float c = s0 + j < S ? c_s[g * 64 + min(s0 + j, 63)] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = fmaf(__uint_as_float(v[j][e]), c, o[e]);
+            }
+        }
+        // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2771-2777)
+        const float inv = 1.f / (l_s[g] + 1e-6f);
+        const uint2 v = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t) b * p.num_heads + hk * G + g) * DH + d) = v;
     }
 }
 

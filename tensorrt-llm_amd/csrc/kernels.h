@@ -33,6 +33,11 @@ LightPlan woq_light_plan(int m, int n, int k, int weight_type);
 void weight_only_gemv_light(const mi355q_weight_only_params& p, LightPlan pl, void* workspace, size_t workspace_bytes,
     hipStream_t stream);
 
+// arrival_ring.hip: zero-initialised, self-resetting arrival words of in-launch reductions, one per 128-byte line
+constexpr int ARRIVAL_WORD_STRIDE = 32; // uint32 words between two arrival words
+size_t arrival_lines_max();
+uint32_t* arrival_lines(size_t count); // device pointer (current device) to `count` words, ARRIVAL_WORD_STRIDE apart
+
 // woq_prefill.hip
 struct WoqArgsHost
 {

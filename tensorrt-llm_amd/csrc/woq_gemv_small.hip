@@ -31,9 +31,8 @@
 //     arrival completes the count sums the tiles in segment order (deterministic) and stores -- no slab reduce launch.
 //     Hand-off per MI355X_MICROARCH.md (Valid forms, row "one lane of each storing workgroup ... the workgroup whose
 //     add came last"): sc1 payload stores, every storing wave drains vmcnt, workgroup barrier, ONE lane's agent-scope
-//     read-modify-write, barrier, sc1 loads.  The arrival word is {epoch : 24, count : 8}: a word whose epoch is not
-//     this launch's (workspace never initialised, or left by another launch) counts as zero, and the completing
-//     workgroup writes 0 back, so a replayed hipGraph (same epoch) starts clean as well.
+//     read-modify-write, barrier, sc1 loads.  The arrival words are arrival_ring.hip's (zero at launch, one per 128-byte
+//     line, put back to zero by the last arrival's own wrapping increment).
 #include "woq_common.h"
 #include <algorithm>
 #include <atomic>
@@ -51,8 +50,7 @@ struct LightArgs
     int seg_tiles;      // k-tiles per segment
     int rounds;         // chunk rounds per workgroup: ceil(seg_tiles / (LW * CH))
     float* records;     // [n-block][segment][16 x 16] fp32 partial tiles (split-K only)
-    uint32_t* arrivals; // [n-block] arrival words (split-K only)
-    uint32_t epoch;     // 1 .. 2^24 - 1
+    uint32_t* arrivals; // one arrival word per n-block (split-K only): arrival_ring.hip, ARRIVAL_WORD_STRIDE apart
     int abl;            // lab build only (MI355Q_GEMV_LIGHT_ABL): ablation bits, see the kernel
 };
 
@@ -499,41 +497,34 @@ __global__ __launch_bounds__(LW * 64) void woq_gemv_light_kernel(LightArgs p)
     __syncthreads();
     if (tid == 0)
     {
-        gu32* word = (gu32*) (p.arrivals + nb);
-        uint32_t cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t next;
-        do
-        {
-            const uint32_t cnt = (cur >> 8) == p.epoch ? (cur & 0xffu) : 0u;
-            next = cnt + 1 == (uint32_t) a.ksplit ? 0u : ((p.epoch << 8) | (cnt + 1));
-        } while (!__hip_atomic_compare_exchange_strong(
-            word, &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        last_flag = next == 0u;
+        // wrapping increment: the arrival that finds ksplit - 1 is the last and leaves the word at zero again
+        gu32* word = (gu32*) (p.arrivals + (size_t) nb * ARRIVAL_WORD_STRIDE);
+        last_flag = __builtin_amdgcn_atomic_inc32(word, (uint32_t) (a.ksplit - 1), __ATOMIC_RELAXED, "agent")
+            == (uint32_t) (a.ksplit - 1);
     }
     __syncthreads();
     if (!last_flag)
         return;
     if (mine)
     {
-        const gf32* base = (const gf32*) (p.records + (size_t) nb * a.ksplit * 256) + om * 16 + on;
+        // sc1 loads, 8 segments in flight; summed in segment order: the same sum whichever workgroup arrives last
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.records + (size_t) nb * a.ksplit * 256, (uint32_t) a.ksplit * 1024);
+        const uint32_t off = (uint32_t) (om * 16 + on) * 4;
         float sum = 0.f;
-        for (int s = 0; s < a.ksplit; ++s) // segment order: the same sum whichever workgroup arrives last
-            sum += __hip_atomic_load(base + s * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1 loads
+        for (int s0 = 0; s0 < a.ksplit; s0 += 8)
+        {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) // past the last segment: beyond the descriptor, reads 0
+                x[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off + (uint32_t) (s0 + j) * 1024, 0, 16));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                sum += x[j];
+        }
         if (a.bias)
             sum += T16<T>::to_float(a.bias[nb * 16 + on]);
         a.out[oi] = T16<T>::from_float(sum);
     }
-}
-
-std::atomic<uint32_t> g_epoch{1};
-
-uint32_t next_epoch()
-{
-    uint32_t e;
-    do
-        e = g_epoch.fetch_add(1, std::memory_order_relaxed) & 0xffffffu;
-    while (e == 0);
-    return e;
 }
 
 template <typename T, int WBITS, int NSZ, int CH, int NBUF, int MF, int LW>
@@ -592,10 +583,11 @@ LightPlan woq_light_plan(int m, int n, int k, int weight_type)
     const int ktiles = k / ktile, nblocks = n / 16;
     static const int lab = lab_env("MI355Q_GEMV_LIGHT") ? atoi(lab_env("MI355Q_GEMV_LIGHT")) : -1; // lab: 0 off, 1 always
     const size_t wbytes = (size_t) n * k * (weight_type == MI355Q_WEIGHT_INT4 ? 1 : 2) / 2;
-    // where it wins (tools/lab_gemv_light.sh): every n-block count that fills the chip without a k split (the in-launch
-    // split below is slower than the persistent kernel's slab reduce at 1280 x 8192: 10.8 against 7.7 us, so it is
-    // reachable from the lab build only); m > 8 streams 4 activation fragments per tile and loses beyond ~24 MB
-    pl.applies = m >= 1 && m <= 16 && ktiles >= 1 && (size_t) 16 * k * 2 < (1ull << 30) && nblocks >= 192
+    // where it wins (tools/lab_gemv_light.sh, tools/lab_splitk.py): every n-block count that fills the chip without a k
+    // split, and fewer n-blocks when K can be cut into segments of >= 16 tiles (1280 x 8192: 5.4 us against the
+    // persistent kernel's 7.9; 8-tile segments lose); m > 8 streams 4 activation fragments per tile and loses beyond ~24 MB
+    pl.applies = m >= 1 && m <= 16 && ktiles >= 1 && (size_t) 16 * k * 2 < (1ull << 30)
+        && (nblocks >= 192 || ktiles >= 32)
         && wbytes <= (m <= 8 ? LIGHT_MAX_WEIGHT_BYTES : LIGHT_MAX_WEIGHT_BYTES_16ROWS);
     if (lab == 0)
         pl.applies = false;
@@ -603,16 +595,17 @@ LightPlan woq_light_plan(int m, int n, int k, int weight_type)
         pl.applies = m >= 1 && m <= 16 && ktiles >= 1;
     if (!pl.applies)
         return pl;
-    // split K only when the n-blocks alone leave most of the chip idle, and never below 16 tiles per workgroup
+    // split K only when the n-blocks alone leave most of the chip idle: towards 512 workgroups, never below 16 tiles
+    // per workgroup (2560 x 8192: 2 / 4 / 8 segments take 7.1 / 6.5 / 9.1 us)
     int ks = 1;
     if (nblocks < 192)
-        ks = std::max(1, std::min({(256 + nblocks - 1) / nblocks, ktiles / 8, 32}));
+        ks = std::max(1, std::min({(512 + nblocks - 1) / nblocks, ktiles / 16, 32}));
     static const int lab_ks = lab_env("MI355Q_GEMV_LIGHT_KS") ? atoi(lab_env("MI355Q_GEMV_LIGHT_KS")) : 0;
     if (lab_ks > 0)
         ks = std::min(lab_ks, ktiles);
     pl.seg_tiles = (ktiles + ks - 1) / ks;
     pl.ksplit = (ktiles + pl.seg_tiles - 1) / pl.seg_tiles; // no empty trailing segment
-    pl.workspace_bytes = pl.ksplit > 1 ? (size_t) nblocks * pl.ksplit * 1024 + (size_t) ((nblocks * 4 + 255) / 256 * 256) : 0;
+    pl.workspace_bytes = pl.ksplit > 1 ? (size_t) nblocks * pl.ksplit * 1024 : 0;
     return pl;
 }
 
@@ -653,8 +646,7 @@ void weight_only_gemv_light(const mi355q_weight_only_params& p, LightPlan pl, vo
     if (pl.ksplit > 1)
     {
         la.records = reinterpret_cast<float*>(workspace);
-        la.arrivals = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (size_t) nblocks * pl.ksplit * 1024);
-        la.epoch = next_epoch();
+        la.arrivals = arrival_lines((size_t) nblocks);
     }
     static const int lab_abl = lab_env("MI355Q_GEMV_LIGHT_ABL") ? atoi(lab_env("MI355Q_GEMV_LIGHT_ABL")) : 0;
     la.abl = lab_abl;
