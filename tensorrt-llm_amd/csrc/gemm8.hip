@@ -651,6 +651,193 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
     });
 }
 
+#ifdef MI355Q_LAB
+// ---------------------------------------------------------------------------------------------
+// LAB BUILD ONLY -- the experiment VERDICT r1 asked for, kept so that its A/B can be re-run (tools/lab_gemm8_ab.py,
+// tools/lab_pmc_gemm8_r2.sh; numbers in profiles/r02_gemm8_ab.txt and DESIGN 4.3).  It LOSES to the 8-wave phased kernel
+// above by 8-10 % in interleaved rounds on one device (2214 / 2440 / 2187 against 2444 / 2656 / 2329 TOPS at
+// 4096x12288x5120 / 8192^3 / cfg3), and with its LDS-DMAs removed altogether (no memory traffic at all) it is only
+// 1-7 % ahead of the phased kernel: the chip holds 1.7-2.1 GHz under this load and the phased kernel is within a few
+// per cent of what a DMA-free MFMA + LDS loop reaches, so the release build keeps the phased kernel.
+// 256 x 256 tile, FOUR waves (2 x 2), wave tile 128 x 128: one wave per SIMD, 256 accumulator registers per lane.
+// Against the 8-wave kernel above (wave tile 128 x 64) a K-tile's fragment reads drop from 192 KiB to 128 KiB per CU
+// (the LDS port, not the matrix pipe, was what the 8-wave kernel filled: VERDICT r1 / DESIGN 4.3), there is ONE barrier
+// per K-tile instead of eight, and no second wave competes for the SIMD's issue slots: the wave itself issues its next
+// fragments' ds_reads and the next-but-one tile's LDS-DMAs in the gaps between its own MFMAs (16 cycles each; one
+// wave per SIMD fits 1-2 ds_read_b128 per MFMA gap for free: MI355X_MICROARCH.md, LDS).
+//   * LDS: 2 K-tiles x [activation rows 0..255 | weight rows 0..255] x 128 B, 16-byte chunks XOR-swizzled with row & 7
+//     (conflict-free for ds_read_b128's lane groups), filled by LDS-DMA: 64 wave-instructions per K-tile, 16 per wave;
+//   * a K-tile is two k-steps of 64 (v_mfma_i32_16x16x64_i8): 64 MFMAs each, the fragments of the step after
+//     (16 ds_read_b128) prefetched into the other half of a 2 x 64-register fragment file;
+//   * step 0 of tile t:  reads F1 <- (t, k-step 1), MFMAs on F0;
+//     then lgkmcnt(0), vmcnt(0) (this wave's DMAs of tile t+1, issued a whole K-tile ago), s_barrier: every wave is
+//     done reading buffer t & 1 and every wave's part of tile t+1 has landed;
+//     step 1 of tile t:  DMAs of tile t+2 -> buffer t & 1, reads F0 <- (t+1, k-step 0), MFMAs on F1.
+//     The DMAs stay in flight across the whole of the next tile's step 0 (2 x 64 MFMAs ~ 2000 cycles).
+// The issue order inside a step is pinned with sched_group_barrier (4 MFMA : 1 ds_read [: 1 DMA]).
+// Requires m % 256 == 0, n % 256 == 0, k % 128 == 0.  Operand roles and the epilogue are those of gemm8_big_kernel.
+__global__ __launch_bounds__(256) void gemm8_w128_kernel(Gemm8Args g, int tiles_m, int tiles_n, int group_m, int abl)
+{
+    constexpr int TK = 128;
+    constexpr int HALF = 256 * TK;  // one operand's rows of a K-tile: 32 KiB
+    constexpr int BUF = 2 * HALF;   // 64 KiB
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF]; // the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int per_group = group_m * tiles_n;
+    const int first_tm = (bid / per_group) * group_m;
+    const int gsz = min(group_m, tiles_m - first_tm);
+    const int tm = first_tm + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+    const size_t m0 = (size_t) tm * 256, n0 = (size_t) tn * 256;
+    const int nk = g.k / TK;
+
+    // ---- staging: wave w fills rows [128 w, 128 w + 128) of the 512-row image (activation rows, then weight rows):
+    // DMA i covers 8 rows, lane -> (row = 8 i + (lane >> 3), stored chunk = lane & 7 <- source chunk ^ (row & 7))
+    const uint8_t* src;
+    {
+        const int row = wave * 128 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((lane >> 3) & 7);
+        src = (row < 256 ? g.A + (m0 + row) * (size_t) g.k : g.B + (n0 + (row - 256)) * (size_t) g.k) + chunk * 16;
+    }
+    const size_t dma_stride = (size_t) 8 * g.k;
+    auto stage_one = [&](int i, int kt)
+    {
+        const int t = min(kt, nk - 1); // past the end: the last tile again (never read; keeps the counts uniform)
+        uint8_t* dst = lds + (kt & 1) * BUF + (wave * 16 + i) * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*) (src + i * dma_stride + (size_t) t * TK), (lds_void_t*) dst, 16, 0, 0);
+    };
+
+    // ---- fragments: lane -> row (l & 15) of a 16-row tile, 16-byte chunk (l >> 4) + 4 ks
+    const int frow = lane & 15, fk = lane >> 4;
+    const int off_ks0 = frow * TK + (((fk) ^ (frow & 7)) << 4), off_ks1 = frow * TK + (((4 + fk) ^ (frow & 7)) << 4);
+    const int a_base = wr * 128 * TK;        // this wave's activation rows
+    const int w_base = HALF + wc * 128 * TK; // this wave's weight rows
+
+    i32x4_t acc[8][8]; // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[i][j] = i32x4_t{0, 0, 0, 0};
+    struct Frags
+    {
+        i32x4_t w[8], a[8];
+    };
+    Frags f0, f1;
+    auto read_one = [&](Frags& f, const uint8_t* buf, int off, int i)
+    {
+        if (i < 8) // the activation fragments first: the next step's first group needs a[0..3] and w[0] only
+            f.a[i] = *reinterpret_cast<const i32x4_t*>(buf + a_base + i * 16 * TK + off);
+        else
+            f.w[i - 8] = *reinterpret_cast<const i32x4_t*>(buf + w_base + (i - 8) * 16 * TK + off);
+    };
+    // The MFMA is written as inline assembly with the accumulator tied in place in the AGPR file ("+a") and the
+    // fragments in VGPRs: with the builtin, hipcc gives D and C different registers and then copies accumulators
+    // through VGPRs at every step boundary (4 moves + s_nop per MFMA at 256 accumulator registers per lane).
+    // Hazards the compiler cannot see inside the asm: none in the loop (an accumulator is touched once per 64 MFMAs;
+    // fragment registers are rewritten a barrier after their last read); the epilogue's first read of the accumulators
+    // is fenced with s_nop below.
+#define G8_MFMA(i, j, f) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"((f).w[i]), "v"((f).a[j]))
+    // one group of a step: 4 MFMAs (n-tile q / 2, m-tiles 4 (q & 1) .. + 3), one fragment read for the next step and,
+    // in step 1, one LDS-DMA of the tile after next; the order is pinned
+#define G8_GROUP(q, fcur, fnext, rbuf, roff, DMA)                                                                      \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        G8_MFMA((q) / 2, 4 * ((q) & 1) + 0, fcur);                                                                     \
+        G8_MFMA((q) / 2, 4 * ((q) & 1) + 1, fcur);                                                                     \
+        if (!(abl & 2))                                                                                                \
+            read_one(fnext, rbuf, roff, q);                                                                            \
+        if (DMA && !(abl & 1))                                                                                         \
+            stage_one(q, kt + 2);                                                                                      \
+        G8_MFMA((q) / 2, 4 * ((q) & 1) + 2, fcur);                                                                     \
+        G8_MFMA((q) / 2, 4 * ((q) & 1) + 3, fcur);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+
+    // prologue: tiles 0 and 1 in flight, tile 0 landed everywhere, F0 <- (0, k-step 0)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        stage_one(i, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        stage_one(i, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        read_one(f0, lds, off_ks0, i);
+
+    for (int kt = 0; kt < nk; ++kt)
+    {
+        const uint8_t* buf = lds + (kt & 1) * BUF;
+        const uint8_t* nbuf = lds + ((kt + 1) & 1) * BUF;
+        // ---- step 0
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            G8_GROUP(q, f0, f1, buf, off_ks1, false);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 1
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            G8_GROUP(q, f1, f0, nbuf, off_ks0, true);
+    }
+#undef G8_GROUP
+#undef G8_MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // the last MFMAs retire before the accumulators are read
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the clamped tail DMAs land before the LDS is released
+
+    const int em = lane & 15, en = (lane >> 4) * 4;
+    float sr[8], sc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        sr[j] = g.alpha_row[g.per_token ? m0 + wr * 128 + j * 16 + em : 0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        gemm8_col_scales(g, n0 + wc * 128 + i * 16 + en, sc[i]);
+    gemm8_dispatch_out(g.out_type, [&](auto out)
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            const size_t row = m0 + wr * 128 + j * 16 + em;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                const size_t col = n0 + wc * 128 + i * 16 + en;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (float) acc[i][j][r] * (sc[i][r] * sr[j]);
+                gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
+            }
+        }
+    });
+}
+
+void launch_w128(const Gemm8Args& g, hipStream_t stream)
+{
+    static const int group_m = lab_env("MI355Q_GEMM8_GROUP_M") ? std::max(1, atoi(lab_env("MI355Q_GEMM8_GROUP_M"))) : 4;
+    const int abl = lab_env("MI355Q_GEMM8_ABL") ? atoi(lab_env("MI355Q_GEMM8_ABL")) : 0; // lab: 1 no DMA, 2 no reads
+    hipLaunchKernelGGL(gemm8_w128_kernel, dim3((g.m / 256) * (g.n / 256)), dim3(256), 0, stream, g, g.m / 256, g.n / 256,
+        group_m, abl);
+}
+#endif // MI355Q_LAB
+
 template <bool FP8>
 void launch_phased(const Gemm8Args& g, hipStream_t stream)
 {
@@ -693,7 +880,16 @@ void launch_tile(int c, const Gemm8Args& g, hipStream_t stream)
 {
     switch (c)
     {
-    case 0: launch_phased<false>(g, stream); break;
+    case 0:
+#ifdef MI355Q_LAB
+        if (lab_env("MI355Q_GEMM8_W128")) // lab: the 4-wave 128 x 128 wave-tile experiment (read per call: A/B in one process)
+        {
+            launch_w128(g, stream);
+            break;
+        }
+#endif
+        launch_phased<false>(g, stream);
+        break;
     case 1: launch_big<256, 128, 4, 2>(g, stream); break;
     default: launch_big<128, 128, 2, 2>(g, stream); break;
     }
