@@ -293,6 +293,22 @@ extern "C"
         int32_t rotary_embedding_max_positions;
         float q_scaling;
         int32_t multi_block_mode;   /* 0: heuristic, >0: force that many kv splits */
+        /* ---- cache addressing beyond the identity map (kernels/kvCacheUtils.h:36-153, 241-338; all zero / NULL =
+         * paged cache, no window, no sink tokens, beam width 1, i.e. what the fields above describe on their own) */
+        int32_t cyclic_attention_window_size; /* Multihead_attention_params::cyclic_attention_window_size
+                                       (decoderMaskedMultiheadAttention.h:120-124); 0 = no window.  With a window the step
+                                       attends to cache slots [0, min(kv length, window)) and writes the new token at
+                                       KVBlockArray::getKVTokenIdx(kv length) (kvCacheUtils.h:109-117) */
+        int32_t sink_token_length;  /* KVBlockArray::mSinkTokens: slots that are never overwritten */
+        int32_t beam_width;         /* 0 or 1: no beams.  > 1: `batch` counts batch x beam rows (batch_beam_idx) */
+        int32_t max_attention_window_size; /* row stride of cache_indirection (:1873-1879) */
+        const int32_t* cache_indirection; /* device [batch / beam_width, beam_width, max_attention_window_size]: the
+                                       beam a cached token of this (sequence, beam) was written by (:1879, :2076, :2441) */
+        const int32_t* input_lengths; /* device [batch]: context lengths; with beams the first input_lengths[b] tokens
+                                       are read from beam 0 (:1497-1498, :1929) */
+        const void* kv_linear_buffer; /* NULL, or the contiguous cache of KVLinearBuffer (kvCacheUtils.h:241-338):
+                                       [batch, 2, Hkv, linear_max_seq_len, Dh] in kv_type; block_pointers is then unused */
+        int32_t linear_max_seq_len;
     } mi355q_decode_attention_params;
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
     mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);
@@ -337,6 +353,9 @@ extern "C"
         float rotary_embedding_scale;
         int32_t rotary_embedding_max_positions;
         float q_scaling;
+        const void* kv_linear_buffer; /* NULL, or the contiguous cache of KVLinearBuffer (kvCacheUtils.h:241-338):
+                                       [batch, 2, Hkv, linear_max_seq_len, Dh] in kv_type; block_pointers is then unused */
+        int32_t linear_max_seq_len;
     } mi355q_context_attention_params;
     size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params);
     mi355q_status mi355q_context_attention(const mi355q_context_attention_params* params, void* stream);

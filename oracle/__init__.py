@@ -423,6 +423,92 @@ def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_
     return out.to(T)
 
 
+class CyclicMap:
+    """The slot map of KVBlockArray / KVLinearBuffer, restated from their constructors and getKVTokenIdx
+    (kernels/kvCacheUtils.h:71-94, 109-117 paged; :277-295, 308-316 linear)."""
+
+    def __init__(self, window, sink, tokens_per_block=None, max_blocks_per_seq=None, linear=False):
+        self.window, self.sink = window, sink
+        if linear:
+            self.bubble = 0                                   # :292
+            self.one_more = False                             # :294
+            self.cyc_len = window - sink                      # :291
+        else:
+            in_last = sink % tokens_per_block                 # :89
+            self.bubble = 0 if in_last == 0 else tokens_per_block - in_last                 # :90
+            self.one_more = (max_blocks_per_seq - 1) * tokens_per_block >= window + self.bubble  # :91
+            self.cyc_len = window + tokens_per_block - sink if self.one_more else window - sink  # :92-93
+
+    def slot(self, t):
+        if t < self.sink:                                     # isSinkToken, :96-99
+            return t
+        return self.sink + self.bubble + (t - self.sink) % self.cyc_len  # :114
+
+
+def decode_attention_slots(qkv, slots, seq_lens, num_heads, num_kv_heads, head_dim, cmap, q_scaling=1.0, rope=None,
+                           rot_dim=0, rope_base=10000.0, rope_scale=1.0, kv_scale_orig_quant=1.0,
+                           kv_scale_quant_orig=1.0, beam_width=1, cache_indir=None, input_lengths=None):
+    """decode_attention over an explicit slot space, with the reference's cyclic / sink addressing and beams
+    (decoderMaskedMultiheadAttentionTemplate.h, POS_SHIFT = false):
+      * slots: torch [batch_beam, 2, Hkv, capacity, Dh] in the cache dtype -- slot s of a sequence, however the
+        cache stores it (paged or linear); updated in place with the new token;
+      * tlength = seq_lens[b] - 1 (:1480-1482); the step reads slots [0, kv_loop_length), kv_loop_length =
+        min(tlength, cyclic_attention_window_size) (:1493, the K loop :1900-1935 and :2056-2080 without POS_SHIFT
+        index the cache by time_now itself);
+      * the new K / V go to slot getKVTokenIdx(tlength) (:1485, :2221-2223, :2478-2480), AFTER the reads (:2207, :2469):
+        a wrapped cyclic cache still shows this step the token it is about to overwrite;
+      * RoPE position is tlength (:1500, POS_SHIFT false);
+      * beams: batch_idx = b // beam_width (:1611); slot t < beam0_context_length is read from row
+        batch_idx * beam_width (:1929), later slots from row batch_idx * beam_width + cache_indir[b][t] (:2076, :2441);
+        beam0_context_length = 0 once tlength > window, else input_lengths[b] (:1497-1498).
+    Same arithmetic as decode_attention otherwise.  Returns out [batch_beam, Hq * Dh] in T."""
+    T = qkv.dtype
+    B = qkv.shape[0]
+    Hq, Hkv, D = num_heads, num_kv_heads, head_dim
+    inv_sqrt = 1.0 / (math.sqrt(D) * q_scaling)
+    x = qkv.float()
+    out = torch.zeros(B, Hq * D, dtype=torch.float32)
+    grp = Hq // Hkv
+    writes = []
+    for b in range(B):
+        tl = int(seq_lens[b]) - 1
+        kv_len = min(tl, cmap.window)
+        q = x[b, :Hq * D].reshape(Hq, D).numpy().copy()
+        k = x[b, Hq * D:(Hq + Hkv) * D].reshape(Hkv, D).numpy().copy()
+        v = x[b, (Hq + Hkv) * D:].reshape(Hkv, D).numpy().copy()
+        if rope is not None:
+            for h in range(Hq):
+                q[h] = apply_rope(q[h], tl, rot_dim, rope, rope_base, rope_scale)
+            for h in range(Hkv):
+                k[h] = apply_rope(k[h], tl, rot_dim, rope, rope_base, rope_scale)
+            q = torch.from_numpy(q).to(T).float().numpy()
+            k = torch.from_numpy(k).to(T).float().numpy()
+        rows = torch.full((kv_len,), b, dtype=torch.long)
+        if beam_width > 1:
+            base = (b // beam_width) * beam_width
+            ctx0 = 0 if tl > cmap.window else int(input_lengths[b])
+            t = torch.arange(kv_len)
+            rows = base + torch.where(t < ctx0, torch.zeros_like(t), cache_indir[b, :kv_len].long())
+        for hk in range(Hkv):
+            idx = torch.arange(kv_len)
+            kc = slots[rows, 0, hk, idx].float() * kv_scale_quant_orig
+            vc = slots[rows, 1, hk, idx].float() * kv_scale_quant_orig
+            kk = torch.cat([kc, torch.from_numpy(k[hk:hk + 1])], 0).double()
+            vv = torch.cat([vc, torch.from_numpy(v[hk:hk + 1])], 0).double()
+            for g in range(grp):
+                h = hk * grp + g
+                logits = (kk @ torch.from_numpy(q[h]).double()).float() * np.float32(inv_sqrt)
+                p = torch.exp(logits - logits.max())
+                o = (p.double() @ vv).float() / (p.sum() + 1e-6)
+                out[b, h * D:(h + 1) * D] = o
+            writes.append((b, hk, cmap.slot(tl), quantize_kv(torch.from_numpy(k[hk]).to(T), slots.dtype, kv_scale_orig_quant),
+                           quantize_kv(torch.from_numpy(v[hk]).to(T), slots.dtype, kv_scale_orig_quant)))
+    for b, hk, s_, kq, vq in writes:  # all rows read before any is written (other beams read this row's slots)
+        slots[b, 0, hk, s_] = kq
+        slots[b, 1, hk, s_] = vq
+    return out.to(T)
+
+
 def decode_attention_c(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_scaling=1.0, rope=None):
     """The same generation step through oracle.c's plain C / OpenMP loops (orc_decode_attention_16): 16-bit caches,
     NeoX RoPE over the whole head or none, no bias, cache not updated.  What bench.py's cpu_baseline leg times."""

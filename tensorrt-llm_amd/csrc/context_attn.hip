@@ -76,9 +76,24 @@ struct CtxArgs
     int batch, max_len, num_heads, num_kv_heads, head_size;
     int rows;                 // total token rows of qkv (padded: B * S)
     int max_blocks, tpb_log2, kv_type; // 0 = T, 1 = int8, 2 = fp8
+    int head_tokens;          // tokens of one head inside a block: tokens_per_block, or linear_max_seq_len
+    char* linear_base;        // KVLinearBuffer::data (kvCacheUtils.h:241-338) or null; one (sequence, K|V) plane is linear_plane_bytes
+    size_t linear_plane_bytes;
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale, score_scale;
 };
+
+// base of the K (kv = 0) or V (kv = 1) block `blk` of sequence b (getKBlockPtr / getVBlockPtr)
+__device__ __forceinline__ char* ctx_block_ptr(const CtxArgs& p, int b, int kv, int blk)
+{
+    if (p.linear_base)
+        return p.linear_base + ((size_t) b * 2 + kv) * p.linear_plane_bytes;
+    return reinterpret_cast<char*>(p.block_ptrs[((size_t) b * 2 + kv) * p.max_blocks + blk]);
+}
+__device__ __forceinline__ bool ctx_has_cache(const CtxArgs& p)
+{
+    return p.block_ptrs != nullptr || p.linear_base != nullptr;
+}
 
 __global__ void ctx_offsets_kernel(const int32_t* lens, int32_t* offsets, int batch)
 {
@@ -160,10 +175,9 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         *reinterpret_cast<uint32_t*>(p.proc + ((size_t) vec * p.rows + row) * D + d) = pack2<T>(xs[e], xs[e + 1]);
     }
     // cache append at position s: block [Hkv][tokens_per_block][Dh]
-    if (p.block_ptrs)
+    if (ctx_has_cache(p))
     {
         const int tpb = 1 << p.tpb_log2;
-        const int64_t* bp = p.block_ptrs + (size_t) b * 2 * p.max_blocks;
         const int blk = s >> p.tpb_log2, tin = s & (tpb - 1);
         const float qs = p.kv_type ? p.kv_scale_orig_quant[0] : 1.f;
         for (int i = threadIdx.x; i < 2 * Hkv * D / 4; i += 256) // 4 consecutive d per thread
@@ -171,8 +185,8 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
             const int e4 = 4 * i;
             const int kv = e4 / (Hkv * D), rem = e4 % (Hkv * D), hk = rem / D, d = rem % D;
             const float* x = xs + (Hq + kv * Hkv + hk) * D + d;
-            const size_t e = ((size_t) hk * tpb + tin) * D + d;
-            char* base = reinterpret_cast<char*>(bp[kv * p.max_blocks + blk]);
+            const size_t e = ((size_t) hk * p.head_tokens + tin) * D + d;
+            char* base = ctx_block_ptr(p, b, kv, blk);
             if (p.kv_type == 0)
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + e) = make_uint2(pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]));
             else if (p.kv_type == 1)
@@ -232,8 +246,8 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
     const int cpv = D / 16; // chunk pairs per vector: 8 / 4
     const int tpb = 1 << p.tpb_log2;
     const int blk = s >> p.tpb_log2, tin = s & (tpb - 1);
-    const int64_t* bp = p.block_ptrs ? p.block_ptrs + (size_t) b * 2 * p.max_blocks : nullptr;
-    const float qs = (p.block_ptrs && p.kv_type) ? p.kv_scale_orig_quant[0] : 1.f;
+    const bool bp = ctx_has_cache(p);
+    const float qs = (bp && p.kv_type) ? p.kv_scale_orig_quant[0] : 1.f;
     for (int it = threadIdx.x; it < nvec * cpv; it += 256)
     {
         const int vec = it / cpv, c = it % cpv;
@@ -308,8 +322,8 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
         if (bp && vec >= Hq)
         {
             const int kv = (vec - Hq) / Hkv, hk = (vec - Hq) % Hkv;
-            const size_t e = ((size_t) hk * tpb + tin) * D;
-            char* base = reinterpret_cast<char*>(bp[kv * p.max_blocks + blk]);
+            const size_t e = ((size_t) hk * p.head_tokens + tin) * D;
+            char* base = ctx_block_ptr(p, b, kv, blk);
             if (p.kv_type == 0)
             {
                 *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + e + d0) = o0;
@@ -652,8 +666,23 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     a.head_size = q.head_size;
     a.max_blocks = q.max_blocks_per_seq;
     a.kv_type = q.kv_type == q.act_type ? 0 : (q.kv_type == MI355Q_INT8 ? 1 : 2);
-    if (q.block_pointers)
+    if (q.kv_linear_buffer)
     {
+        MQ_CHECK(q.linear_max_seq_len >= q.max_context_length, "max_context_length %d exceeds the linear cache (%d tokens per sequence)",
+            q.max_context_length, q.linear_max_seq_len);
+        MQ_CHECK(q.kv_type == q.act_type || q.kv_type == MI355Q_INT8 || q.kv_type == MI355Q_FP8, "kv cache type %d", q.kv_type);
+        if (a.kv_type)
+            MQ_CHECK(q.kv_scale_orig_quant, "8-bit kv cache needs kv_scale_orig_quant");
+        a.block_ptrs = nullptr;
+        a.max_blocks = 1;
+        a.tpb_log2 = 30; // one "block" holds the whole sequence
+        a.head_tokens = q.linear_max_seq_len;
+        a.linear_base = static_cast<char*>(const_cast<void*>(q.kv_linear_buffer));
+        a.linear_plane_bytes = (size_t) q.num_kv_heads * q.linear_max_seq_len * q.head_size * (a.kv_type ? 1 : 2);
+    }
+    else if (q.block_pointers)
+    {
+        a.head_tokens = q.tokens_per_block;
         MQ_CHECK(q.tokens_per_block > 0 && (q.tokens_per_block & (q.tokens_per_block - 1)) == 0,
             "tokens_per_block must be a power of 2 (kvCacheUtils.h:80-82), got %d", q.tokens_per_block);
         MQ_CHECK(q.max_context_length <= q.max_blocks_per_seq * q.tokens_per_block,

@@ -27,9 +27,13 @@ namespace
 {
 
 
-template <typename T, int KVT, int DH, int G, int U>
+// GEN = the general form: one workgroup per QUERY head (G = 1; any q / kv head ratio), every lane resolves its own
+// token's block pointer, so beams (cache_indirection, decoderMaskedMultiheadAttentionTemplate.h:1873-1879, 2076, 2441)
+// and tiles that straddle blocks work; the kv group's first query head appends the new token.
+template <typename T, int KVT, int DH, int G, int U, bool GEN = false>
 __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
 {
+    static_assert(!GEN || (G == 1 && U == 1), "the general form serves one query head per workgroup");
     constexpr int KVB = KVT == 0 ? 2 : 1;  // bytes per cache element
     constexpr int E = 16 / KVB;            // cache elements per lane per load
     constexpr int LPT = DH / E;            // lanes per token row
@@ -52,14 +56,19 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x % p.splits;
     const int bh = blockIdx.x / p.splits;
-    const int hk = bh % p.num_kv_heads;
-    const int b = bh / p.num_kv_heads;
     const int Hq = p.num_heads;
+    const int heads_in_grid = GEN ? Hq : p.num_kv_heads;
+    const int hg = bh % heads_in_grid;
+    const int b = bh / heads_in_grid;
+    const int hk = GEN ? hg / p.q_per_kv : hg;   // kv head
+    const int hq0 = GEN ? hg : hg * G;           // first query head of this workgroup
     const int tl = p.seq_lens[b] - 1; // cached tokens; the current token sits at position tl
+    const int kv_len = min(tl, p.kv_window); // slots [0, kv_len) are read (Template.h:1493)
     const int tpb = 1 << p.tpb_log2;
     const bool last_split = split == p.splits - 1;
+    const bool appends = !GEN || hg % p.q_per_kv == 0;
 
-    stage_new_token<T, DH, G>(p, b, hk, tl, smem);
+    stage_new_token<T, DH, G>(p, b, hq0, hk, tl, smem);
 
     const int ts = lane / LPT;  // token slot inside a wave-load
     const int ch = lane % LPT;  // 16-byte chunk of the row
@@ -110,70 +119,107 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
             for (int e = 0; e < E; ++e)
                 acc[g][e] = vf[e];
         }
-        // append to the cache at position tl (cyclic/sink addressing not enabled: identity map)
-        const int64_t* bp = p.block_ptrs + (size_t) b * 2 * p.max_blocks;
-        const int blk = tl >> p.tpb_log2;
-        const size_t row = ((size_t) hk * tpb + (tl & (tpb - 1))) * DH * KVB + (size_t) ch * 16;
-        uint4 kw, vw;
-        if constexpr (KVT == 0)
-        {
-            uint32_t* kk = reinterpret_cast<uint32_t*>(&kw);
-            uint32_t* vv = reinterpret_cast<uint32_t*>(&vw);
-#pragma unroll
-            for (int e = 0; e < EP; ++e)
-            {
-                kk[e] = pack2<T>(kf[2 * e], kf[2 * e + 1]);
-                vv[e] = pack2<T>(vf[2 * e], vf[2 * e + 1]);
-            }
-        }
-        else
-        {
-            const float qs = p.kv_scale_orig_quant[0];
-            uint8_t* kk = reinterpret_cast<uint8_t*>(&kw);
-            uint8_t* vv = reinterpret_cast<uint8_t*>(&vw);
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-            {
-                kk[e] = KVT == 1 ? float_to_int8_sat(kf[e] * qs) : float_to_fp8(kf[e] * qs);
-                vv[e] = KVT == 1 ? float_to_int8_sat(vf[e] * qs) : float_to_fp8(vf[e] * qs);
-            }
-        }
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(bp[blk]) + row) = kw;
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(bp[p.max_blocks + blk]) + row) = vw;
     }
 
-    // ---- stream the cached tokens of this split
+    // ---- the cache append, at slot getKVTokenIdx(tl) (Template.h:1485, 2221-2223, 2478-2480).  When the cyclic cache
+    // has wrapped, that slot still holds the oldest token of the window, which this step attends to as well (the
+    // reference reads kv_loop_length slots and overwrites afterwards, :2207, :2469): then the split that reads the
+    // slot writes it, after its own loop and a barrier; otherwise nobody reads the slot and the last split writes early.
+    const int slot = kv_slot(p, tl);
+    const bool wrapped = slot < kv_len;
+    auto append_new_token = [&]()
     {
-        const int ntiles = (tl + TILE - 1) / TILE;
+        if (wave == 0 && ts == 0 && appends)
+        {
+            const int blk = slot >> p.tpb_log2;
+            const size_t row = ((size_t) hk * p.head_tokens + (slot & (tpb - 1))) * DH * KVB + (size_t) ch * 16;
+            uint4 kw, vw;
+            if constexpr (KVT == 0)
+            {
+                uint32_t* kk = reinterpret_cast<uint32_t*>(&kw);
+                uint32_t* vv = reinterpret_cast<uint32_t*>(&vw);
+#pragma unroll
+                for (int e = 0; e < EP; ++e)
+                {
+                    kk[e] = pack2<T>(k_s[ch * E + 2 * e], k_s[ch * E + 2 * e + 1]);
+                    vv[e] = pack2<T>(v_s[ch * E + 2 * e], v_s[ch * E + 2 * e + 1]);
+                }
+            }
+            else
+            {
+                const float qs = p.kv_scale_orig_quant[0];
+                uint8_t* kk = reinterpret_cast<uint8_t*>(&kw);
+                uint8_t* vv = reinterpret_cast<uint8_t*>(&vw);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                {
+                    kk[e] = KVT == 1 ? float_to_int8_sat(k_s[ch * E + e] * qs) : float_to_fp8(k_s[ch * E + e] * qs);
+                    vv[e] = KVT == 1 ? float_to_int8_sat(v_s[ch * E + e] * qs) : float_to_fp8(v_s[ch * E + e] * qs);
+                }
+            }
+            *reinterpret_cast<uint4*>(kv_block_ptr(p, b, 0, blk) + row) = kw;
+            *reinterpret_cast<uint4*>(kv_block_ptr(p, b, 1, blk) + row) = vw;
+        }
+    };
+    if (!wrapped && last_split)
+        append_new_token();
+
+    // ---- stream the cached tokens of this split
+    bool writes_after_loop = false;
+    {
+        const int ntiles = (kv_len + TILE - 1) / TILE;
         const int tps = (ntiles + p.splits - 1) / p.splits;
         const int tile_end = min(ntiles, (split + 1) * tps);
-        const int64_t* bp = p.block_ptrs + (size_t) b * 2 * p.max_blocks;
-        const size_t head_off = (size_t) hk * tpb * DH * KVB + (size_t) ch * 16;
+        writes_after_loop = wrapped && (slot / TILE) / tps == split;
+        const size_t head_off = (size_t) hk * p.head_tokens * DH * KVB + (size_t) ch * 16;
+        // beams: tokens before beam0_context_length come from beam 0 of the batch entry, later ones from the beam
+        // cache_indir names; with a wrapped cyclic cache the context may be overwritten: 0 (Template.h:1497-1498)
+        const int beam_w = GEN ? max(p.beam_width, 1) : 1;
+        const int seq0 = (b / beam_w) * beam_w;
+        const int beam0_ctx = (GEN && beam_w > 1) ? (tl > p.kv_window ? 0 : p.input_lengths[b]) : 0;
+        const int32_t* indir = (GEN && beam_w > 1) ? p.cache_indir + (size_t) b * p.indir_stride : nullptr;
 
         for (int tile = split * tps + wave; tile < tile_end; tile += NW)
         {
             const int t0 = tile * TILE;
-            const int blk = t0 >> p.tpb_log2;
-            const char* kbase = reinterpret_cast<const char*>(bp[blk]) + head_off;
-            const char* vbase = reinterpret_cast<const char*>(bp[p.max_blocks + blk]) + head_off;
-            const int tin = (t0 & (tpb - 1)) + ts;
-
             uint4 kreg[U], vreg[U];
             bool valid[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            if constexpr (GEN)
             {
-                valid[u] = t0 + u * TPW + ts < tl;
-                kreg[u] = make_uint4(0, 0, 0, 0);
-                if (valid[u])
-                    kreg[u] = *reinterpret_cast<const uint4*>(kbase + (size_t) (tin + u * TPW) * DH * KVB);
+                const int t = t0 + ts;
+                valid[0] = t < kv_len;
+                kreg[0] = make_uint4(0, 0, 0, 0);
+                vreg[0] = make_uint4(0, 0, 0, 0);
+                if (valid[0])
+                {
+                    const int seq = beam_w > 1 ? seq0 + (t < beam0_ctx ? 0 : indir[t]) : b;
+                    const int blk = t >> p.tpb_log2;
+                    const size_t off = head_off + (size_t) (t & (tpb - 1)) * DH * KVB;
+                    kreg[0] = *reinterpret_cast<const uint4*>(kv_block_ptr(p, seq, 0, blk) + off);
+                    vreg[0] = *reinterpret_cast<const uint4*>(kv_block_ptr(p, seq, 1, blk) + off);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            else
             {
-                vreg[u] = make_uint4(0, 0, 0, 0);
-                if (valid[u])
-                    vreg[u] = *reinterpret_cast<const uint4*>(vbase + (size_t) (tin + u * TPW) * DH * KVB);
+                const int blk = t0 >> p.tpb_log2;
+                const char* kbase = kv_block_ptr(p, b, 0, blk) + head_off;
+                const char* vbase = kv_block_ptr(p, b, 1, blk) + head_off;
+                const int tin = (t0 & (tpb - 1)) + ts;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    valid[u] = t0 + u * TPW + ts < kv_len;
+                    kreg[u] = make_uint4(0, 0, 0, 0);
+                    if (valid[u])
+                        kreg[u] = *reinterpret_cast<const uint4*>(kbase + (size_t) (tin + u * TPW) * DH * KVB);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    vreg[u] = make_uint4(0, 0, 0, 0);
+                    if (valid[u])
+                        vreg[u] = *reinterpret_cast<const uint4*>(vbase + (size_t) (tin + u * TPW) * DH * KVB);
+                }
             }
 
             float s[G][U];
@@ -262,6 +308,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
         }
     }
 
+    if (wrapped) // wave-uniform, the same in every wave of the workgroup
+    {
+        __syncthreads(); // every wave of this split has read the slot
+        if (writes_after_loop)
+            append_new_token();
+    }
+
     // ---- merge the TPW token slots of the wave (lanes with equal `ch`)
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -306,7 +359,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
         }
     }
     __syncthreads();
-    finish_states<T, G, DH, NW * 64, NW>(p, b, hk, split, red);
+    finish_states<T, G, DH, NW * 64, NW>(p, b * heads_in_grid + hg, (size_t) b * Hq + hq0, split, red);
 }
 
 int ilog2(int x)
@@ -317,17 +370,18 @@ int ilog2(int x)
     return l;
 }
 
-int choose_splits(const mi355q_decode_attention_params& q, int tile)
+struct Plan;
+int choose_splits(const mi355q_decode_attention_params& q, const Plan& pl);
+int choose_splits_impl(const mi355q_decode_attention_params& q, int tile, int wgs, int max_kv_len)
 {
     // every path ends at min(64, tiles): the merge holds 64 rescale factors, and a split without a tile is wasted
-    const int max_tiles = std::max(1, (q.max_seq_len + tile - 1) / tile);
+    const int max_tiles = std::max(1, (max_kv_len + tile - 1) / tile);
     const int cap = std::min(64, max_tiles);
     if (q.multi_block_mode > 0)
         return std::min(q.multi_block_mode, cap);
     static const int env_splits = lab_env("MI355Q_ATTN_SPLITS") ? atoi(lab_env("MI355Q_ATTN_SPLITS")) : 0; // lab
     if (env_splits > 0)
         return std::min(env_splits, cap);
-    const int wgs = q.batch * q.num_kv_heads;
     // aim for 2 workgroups per CU, never less than NW tiles per workgroup (a workgroup's fixed cost -- staging the new
     // token, the cross-wave merge, its partial state -- is ~8 us: at batch 64 x 1 kv head, ctx 2048, 8 splits take
     // 16 us, 16 splits 23 us)
@@ -408,39 +462,136 @@ void dispatch_kv(const mi355q_decode_attention_params& q, const DecodeArgs& a, i
         MQ_UNSUPPORTED("decode attention: kv cache type %d", q.kv_type);
 }
 
+// the general form (decode_attn_kernel<..., GEN = true>): head sizes 32 .. 256, one workgroup per query head
+template <typename T, int KVT, int DH>
+void launch_general(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStream_t stream)
+{
+    const int grid = q.batch * q.num_heads * a.splits;
+    hipLaunchKernelGGL((decode_attn_kernel<T, KVT, DH, 1, 1, true>), dim3(grid), dim3(NW * 64), 0, stream, a);
+}
+
+template <typename T, int KVT>
+void dispatch_general_dh(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStream_t s)
+{
+    switch (q.head_size)
+    {
+    case 32: launch_general<T, KVT, 32>(q, a, s); break;
+    case 64: launch_general<T, KVT, 64>(q, a, s); break;
+    case 128: launch_general<T, KVT, 128>(q, a, s); break;
+    case 256: launch_general<T, KVT, 256>(q, a, s); break;
+    default: MQ_UNSUPPORTED("decode attention: head_size %d not built (32, 64, 128, 256)", q.head_size);
+    }
+}
+
+template <typename T>
+void dispatch_general(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStream_t s)
+{
+    if (q.kv_type == q.act_type)
+        dispatch_general_dh<T, 0>(q, a, s);
+    else if (q.kv_type == MI355Q_INT8)
+        dispatch_general_dh<T, 1>(q, a, s);
+    else if (q.kv_type == MI355Q_FP8)
+        dispatch_general_dh<T, 2>(q, a, s);
+    else
+        MQ_UNSUPPORTED("decode attention: kv cache type %d", q.kv_type);
+}
+
 #include "decode_attn_gqa.inc"
 
 struct Plan
 {
     int kvb, u, tile, splits;
-    bool gqa;
+    bool gqa, general;
+    int groups;   // workgroup groups that share one K/V stream = arrival words = partial-record groups
+    int capacity; // cache slots per sequence
+    int window, sink, bubble, cyc_len; // KVBlockArray / KVLinearBuffer constructor (kvCacheUtils.h:71-94, 277-295)
 };
+
+int choose_splits(const mi355q_decode_attention_params& q, const Plan& pl)
+{
+    return choose_splits_impl(q, pl.tile, pl.groups, std::min(q.max_seq_len, pl.window));
+}
 
 Plan make_plan(const mi355q_decode_attention_params& q)
 {
     MQ_CHECK(q.act_type == MI355Q_HALF || q.act_type == MI355Q_BF16, "act_type %d", q.act_type);
     MQ_CHECK(q.batch > 0 && q.num_heads > 0 && q.num_kv_heads > 0, "bad sizes");
     MQ_CHECK(q.num_heads % q.num_kv_heads == 0, "num_heads %% num_kv_heads");
-    MQ_CHECK(q.tokens_per_block > 0 && (q.tokens_per_block & (q.tokens_per_block - 1)) == 0,
-        "tokens_per_block must be a power of 2 (kvCacheUtils.h:80-82), got %d", q.tokens_per_block);
-    MQ_CHECK(q.max_seq_len >= 1 && q.max_seq_len <= q.max_blocks_per_seq * q.tokens_per_block,
-        "max_seq_len %d exceeds the block table (%d x %d)", q.max_seq_len, q.max_blocks_per_seq, q.tokens_per_block);
-    Plan pl;
+    const bool linear = q.kv_linear_buffer != nullptr;
+    Plan pl{};
+    if (linear)
+    {
+        MQ_CHECK(q.linear_max_seq_len > 0, "linear_max_seq_len %d", q.linear_max_seq_len);
+        pl.capacity = q.linear_max_seq_len;
+    }
+    else
+    {
+        MQ_CHECK(q.tokens_per_block > 0 && (q.tokens_per_block & (q.tokens_per_block - 1)) == 0,
+            "tokens_per_block must be a power of 2 (kvCacheUtils.h:80-82), got %d", q.tokens_per_block);
+        MQ_CHECK(q.max_blocks_per_seq > 0, "max_blocks_per_seq %d", q.max_blocks_per_seq);
+        pl.capacity = q.max_blocks_per_seq * q.tokens_per_block;
+    }
+    // the cyclic map (KVBlockArray ctor :89-93, KVLinearBuffer ctor :291-294)
+    pl.window = q.cyclic_attention_window_size > 0 ? q.cyclic_attention_window_size : pl.capacity;
+    pl.sink = q.sink_token_length;
+    MQ_CHECK(pl.sink >= 0 && pl.sink < pl.window, "sink_token_length %d against a window of %d", pl.sink, pl.window);
+    if (linear)
+    {
+        pl.bubble = 0;
+        pl.cyc_len = pl.window - pl.sink;
+    }
+    else
+    {
+        const int in_last = pl.sink % q.tokens_per_block;
+        pl.bubble = in_last == 0 ? 0 : q.tokens_per_block - in_last;
+        const bool one_more = (q.max_blocks_per_seq - 1) * q.tokens_per_block >= pl.window + pl.bubble;
+        pl.cyc_len = one_more ? pl.window + q.tokens_per_block - pl.sink : pl.window - pl.sink;
+    }
+    MQ_CHECK(pl.sink + pl.bubble + pl.cyc_len <= pl.capacity, "the cyclic cache (sink %d + bubble %d + %d slots) exceeds the %d slots of a sequence",
+        pl.sink, pl.bubble, pl.cyc_len, pl.capacity);
+    MQ_CHECK(pl.window <= pl.capacity, "attention window %d exceeds the %d cache slots of a sequence", pl.window, pl.capacity);
+    // without a window every token needs its own slot
+    if (q.cyclic_attention_window_size <= 0)
+        MQ_CHECK(q.max_seq_len >= 1 && q.max_seq_len <= pl.capacity, "max_seq_len %d exceeds the cache (%d slots per sequence)",
+            q.max_seq_len, pl.capacity);
+    else
+        MQ_CHECK(q.max_seq_len >= 1, "max_seq_len %d", q.max_seq_len);
+    const int beams = q.beam_width > 1 ? q.beam_width : 1;
+    if (beams > 1)
+    {
+        MQ_CHECK(q.cache_indirection && q.input_lengths, "beam_width %d needs cache_indirection and input_lengths", beams);
+        MQ_CHECK(q.batch % beams == 0, "batch %d is not a multiple of beam_width %d", q.batch, beams);
+        MQ_CHECK(q.max_attention_window_size >= std::min(q.max_seq_len - 1, pl.window),
+            "cache_indirection rows of %d entries are shorter than the %d slots read", q.max_attention_window_size,
+            std::min(q.max_seq_len - 1, pl.window));
+    }
     pl.kvb = q.kv_type == q.act_type ? 2 : 1;
-    MQ_CHECK(q.head_size == 64 || q.head_size == 128, "head_size %d not built (64, 128)", q.head_size);
-    pl.gqa = gqa_mfma_applies(q);
+    MQ_CHECK(q.head_size == 32 || q.head_size == 64 || q.head_size == 128 || q.head_size == 256,
+        "head_size %d not built (32, 64, 128, 256)", q.head_size);
+    const int g = q.num_heads / q.num_kv_heads;
+    const int tpw = 64 / (q.head_size / (16 / pl.kvb));
+    const int tpb = linear ? (1 << 30) : q.tokens_per_block;
+    pl.gqa = beams == 1 && gqa_mfma_applies(q);
+    // the general form: beams, head sizes / head ratios the grouped kernels are not built for, tiny blocks
+    pl.general = !pl.gqa
+        && (beams > 1 || !(g == 1 || g == 2 || g == 4 || g == 8) || !(q.head_size == 64 || q.head_size == 128) || tpb < tpw);
+    pl.groups = q.batch * (pl.general ? q.num_heads : q.num_kv_heads);
     if (pl.gqa)
     {
         pl.u = 1;
         pl.tile = GQA_STEP;
-        pl.splits = choose_splits(q, pl.tile);
-        return pl;
     }
-    const int tpw = 64 / (q.head_size / (16 / pl.kvb));
-    MQ_CHECK(q.tokens_per_block >= tpw, "tokens_per_block %d < %d rows per wave-load", q.tokens_per_block, tpw);
-    pl.u = pick_unroll(q.head_size, pl.kvb, q.tokens_per_block, q.num_heads / q.num_kv_heads);
-    pl.tile = tpw * pl.u;
-    pl.splits = choose_splits(q, pl.tile);
+    else if (pl.general)
+    {
+        pl.u = 1;
+        pl.tile = tpw;
+    }
+    else
+    {
+        pl.u = pick_unroll(q.head_size, pl.kvb, tpb, g);
+        pl.tile = tpw * pl.u;
+    }
+    pl.splits = choose_splits(q, pl);
     return pl;
 }
 
@@ -448,16 +599,17 @@ Plan make_plan(const mi355q_decode_attention_params& q)
 
 namespace
 {
-// floats of one (sequence, kv head) group: its partial records padded to a 128-byte line
-size_t group_floats(const mi355q_decode_attention_params& q, int splits)
+// floats of one group (the query heads one workgroup serves: the kv group, or one head in the general form): its
+// partial records padded to a 128-byte line
+size_t group_floats(const mi355q_decode_attention_params& q, const Plan& pl)
 {
-    const size_t g = (size_t) (q.num_heads / q.num_kv_heads);
-    return ((size_t) splits * g * (q.head_size + PART_PAD) + 31) / 32 * 32;
+    const size_t g = pl.general ? 1 : (size_t) (q.num_heads / q.num_kv_heads);
+    return ((size_t) pl.splits * g * (q.head_size + PART_PAD) + 31) / 32 * 32;
 }
 // bytes of the split-KV area of one call
-size_t partials_bytes(const mi355q_decode_attention_params& q, int splits)
+size_t partials_bytes(const mi355q_decode_attention_params& q, const Plan& pl)
 {
-    return (size_t) q.batch * q.num_kv_heads * group_floats(q, splits) * sizeof(float);
+    return (size_t) pl.groups * group_floats(q, pl) * sizeof(float);
 }
 } // namespace
 
@@ -468,7 +620,7 @@ size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
     // for any smaller batch enqueued later (TensorRT asks once, at configure time, with max shapes)
     const size_t rows = q.multi_block_mode > 0 ? (size_t) q.batch * q.multi_block_mode
                                                : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
-    const size_t groups = (size_t) q.batch * q.num_kv_heads;
+    const size_t groups = (size_t) q.batch * q.num_heads; // the general form has one group per query head
     // records + the per-group padding to a line
     return rows * q.num_heads * (q.head_size + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);
 }
@@ -498,7 +650,8 @@ extern "C" const unsigned long long* mi355q_lab_decode_stamps()
 void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStream_t stream)
 {
     Plan pl = make_plan(q);
-    MQ_CHECK(q.qkv && q.out && q.sequence_lengths && q.block_pointers, "null tensor");
+    const bool linear = q.kv_linear_buffer != nullptr;
+    MQ_CHECK(q.qkv && q.out && q.sequence_lengths && (linear || q.block_pointers), "null tensor");
     MQ_CHECK(((uintptr_t) q.qkv & 15) == 0 && ((uintptr_t) q.qkv_bias & 15) == 0,
         "qkv / qkv_bias must be 16-byte aligned (the new token is staged with 16-byte loads)");
     if (pl.kvb == 1)
@@ -514,8 +667,20 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
     a.batch = q.batch;
     a.num_heads = q.num_heads;
     a.num_kv_heads = q.num_kv_heads;
-    a.max_blocks = q.max_blocks_per_seq;
-    a.tpb_log2 = ilog2(q.tokens_per_block);
+    a.max_blocks = linear ? 1 : q.max_blocks_per_seq;
+    a.tpb_log2 = linear ? 30 : ilog2(q.tokens_per_block); // one "block" holds the whole sequence of a linear cache
+    a.head_tokens = linear ? q.linear_max_seq_len : q.tokens_per_block;
+    a.linear_base = static_cast<const char*>(q.kv_linear_buffer);
+    a.linear_plane_bytes = linear ? (size_t) q.num_kv_heads * q.linear_max_seq_len * q.head_size * pl.kvb : 0;
+    a.kv_window = pl.window;
+    a.sink = pl.sink;
+    a.bubble = pl.bubble;
+    a.cyc_len = pl.cyc_len;
+    a.q_per_kv = q.num_heads / q.num_kv_heads;
+    a.beam_width = q.beam_width > 1 ? q.beam_width : 1;
+    a.indir_stride = q.max_attention_window_size;
+    a.cache_indir = q.cache_indirection;
+    a.input_lengths = q.input_lengths;
     a.splits = pl.splits;
     a.pos_type = q.position_embedding_type;
     a.rot_dim = q.rotary_embedding_dim;
@@ -532,12 +697,12 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
             q.position_embedding_type);
     if (pl.splits > 1)
     {
-        const size_t need = partials_bytes(q, pl.splits);
+        const size_t need = partials_bytes(q, pl);
         MQ_CHECK(q.workspace && q.workspace_bytes >= need, "workspace too small: %zu < %zu", q.workspace_bytes, need);
         MQ_CHECK(((uintptr_t) q.workspace & 127) == 0, "workspace must be 128-byte aligned");
-        a.group_floats = (int) group_floats(q, pl.splits);
+        a.group_floats = (int) group_floats(q, pl);
         a.partials = reinterpret_cast<float*>(q.workspace);
-        a.arrivals = arrival_lines((size_t) q.batch * q.num_kv_heads);
+        a.arrivals = arrival_lines((size_t) pl.groups);
     }
 #ifdef MI355Q_LAB
     a.stamps = lab_decode_stamps();
@@ -548,6 +713,13 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
             dispatch_gqa<bf16_t>(q, a, stream);
         else
             dispatch_gqa<f16_t>(q, a, stream);
+    }
+    else if (pl.general)
+    {
+        if (q.act_type == MI355Q_BF16)
+            dispatch_general<bf16_t>(q, a, stream);
+        else
+            dispatch_general<f16_t>(q, a, stream);
     }
     else if (q.act_type == MI355Q_BF16)
         dispatch_kv<bf16_t>(q, a, pl.u, stream);
@@ -604,7 +776,7 @@ void masked_multihead_attention_static(const mi355q_decode_attention_params& q, 
     if (pl.splits > 1)
     {
         // what THIS call's partials take (not the max-shape bound of the workspace query)
-        const size_t need = partials_bytes(q, pl.splits);
+        const size_t need = partials_bytes(q, pl);
         MQ_CHECK(need <= DECODE_SCRATCH_BYTES,
             "split-KV partials of this call (%zu bytes: batch %d x %d heads x %d splits) exceed the %zu-byte static scratch; "
             "use mi355q_masked_multihead_attention with a workspace",

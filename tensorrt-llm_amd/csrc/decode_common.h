@@ -31,6 +31,16 @@ struct DecodeArgs
     int batch, num_heads, num_kv_heads;
     int max_blocks, tpb_log2;
     int splits;
+    // cache addressing (kvCacheUtils.h:36-153, 241-338).  Slots read: [0, min(kv length, kv_window)); the new token goes
+    // to kv_slot(kv length).  Without a window these are the identity (kv_window = capacity, sink = bubble = 0).
+    int kv_window, sink, bubble, cyc_len;
+    int head_tokens;          // tokens of one head inside a block: tokens_per_block, or linear_max_seq_len
+    const char* linear_base;  // KVLinearBuffer::data or null; one (sequence, K|V) plane is linear_plane_bytes
+    size_t linear_plane_bytes;
+    // the general kernel only (one workgroup per QUERY head): beams, any q / kv head ratio
+    int q_per_kv, beam_width, indir_stride;
+    const int32_t* cache_indir;
+    const int32_t* input_lengths;
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale;
     float score_scale; // 1 / (sqrt(Dh) * q_scaling)
@@ -55,6 +65,20 @@ struct DecodeArgs
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+// KVBlockArray / KVLinearBuffer::getKVTokenIdx (kvCacheUtils.h:109-117, 308-316): the cache slot of token t
+__device__ __forceinline__ int kv_slot(const DecodeArgs& p, int t)
+{
+    return t < p.sink ? t : p.sink + p.bubble + (t - p.sink) % p.cyc_len;
+}
+
+// base of the K (kv = 0) or V (kv = 1) block `blk` of sequence `seq` (getKBlockPtr / getVBlockPtr, :101-137, :302-331)
+__device__ __forceinline__ char* kv_block_ptr(const DecodeArgs& p, int seq, int kv, int blk)
+{
+    if (p.linear_base)
+        return const_cast<char*>(p.linear_base) + ((size_t) seq * 2 + kv) * p.linear_plane_bytes;
+    return reinterpret_cast<char*>(p.block_ptrs[((size_t) seq * 2 + kv) * p.max_blocks + blk]);
+}
 
 template <typename T>
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c);
@@ -138,7 +162,7 @@ struct NewTokenRegs
 };
 
 template <typename T, int DH, int G>
-__device__ __forceinline__ void issue_new_token(const DecodeArgs& p, int b, int hk, NewTokenRegs<G, DH>& r)
+__device__ __forceinline__ void issue_new_token(const DecodeArgs& p, int b, int hq0, int hk, NewTokenRegs<G, DH>& r)
 {
     const int tid = threadIdx.x;
     const int Hq = p.num_heads, Hkv = p.num_kv_heads;
@@ -149,7 +173,7 @@ __device__ __forceinline__ void issue_new_token(const DecodeArgs& p, int b, int 
     {
         const int v = min(tid + t * NW * 64, NewTokenRegs<G, DH>::NV - 1); // past the end: a valid vector, not stored
         const int vec = (v * 8) / DH, d = (v * 8) % DH;
-        const int off = vec < G ? (hk * G + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
+        const int off = vec < G ? (hq0 + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
         r.x[t] = *reinterpret_cast<const uint4*>(qkv + off);
         r.bias[t] = *reinterpret_cast<const uint4*>(bias + off);
     }
@@ -247,10 +271,10 @@ __device__ __forceinline__ void stage_new_token(
 }
 
 template <typename T, int DH, int G>
-__device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int hk, int tl, float* smem)
+__device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int hq0, int hk, int tl, float* smem)
 {
     NewTokenRegs<G, DH> r;
-    issue_new_token<T, DH, G>(p, b, hk, r);
+    issue_new_token<T, DH, G>(p, b, hq0, hk, r);
     stage_new_token<T, DH, G>(p, r, tl, smem, rope_early_pow(p));
 }
 
@@ -271,7 +295,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dec_rsrc(const void* p, size_t
 }
 
 // The end of a decode workgroup: merge its NSTATES partial states (LDS `red`: [NSTATES][G][DH + 2] = acc | m | l) and
-// either write the output (no split) or take part in the split-KV merge INSIDE the launch (the reference does the same
+// (`group` = the workgroups that share the K/V stream, `out_head0` = row of the first output head) either write the output (no split) or take part in the split-KV merge INSIDE the launch (the reference does the same
 // with its block_counter, decoderMaskedMultiheadAttentionTemplate.h:2614-2786; a second kernel used to do it here).
 // A thread owns 4 consecutive d of one head.  Split-KV: the workgroup publishes its G merged states into its records
 // of the (sequence, kv head) group -- 16-byte write-through (sc1) stores --, every storing wave drains vmcnt, barrier,
@@ -282,14 +306,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dec_rsrc(const void* p, size_t
 // back to zero by the last arrival's own wrapping increment -- one round trip, no reset pass, graph replay safe).
 // `red` is reused as scratch (>= 1 + G * 65 floats).
 template <typename T, int G, int DH, int THREADS, int NSTATES>
-__device__ __forceinline__ void finish_states(const DecodeArgs& p, int b, int hk, int split, float* red)
+__device__ __forceinline__ void finish_states(const DecodeArgs& p, int group, size_t out_head0, int split, float* red)
 {
     constexpr int RS = DH + 2;           // LDS row stride
     constexpr int REC = DH + PART_PAD;   // global record stride (floats)
     const int tid = threadIdx.x;
     const size_t grp_bytes = (size_t) p.group_floats * sizeof(float);
     const __amdgpu_buffer_rsrc_t grp
-        = dec_rsrc(p.partials + ((size_t) b * p.num_kv_heads + hk) * p.group_floats, p.splits > 1 ? grp_bytes : 0);
+        = dec_rsrc(p.partials + (size_t) group * p.group_floats, p.splits > 1 ? grp_bytes : 0);
     for (int i = tid; i < G * DH / 4; i += THREADS)
     {
         const int g = i / (DH / 4), d = (i % (DH / 4)) * 4;
@@ -314,7 +338,7 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int b, int hk
             // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2285-2290)
             const float inv = 1.f / (ll + 1e-6f);
             const uint2 v = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t) b * p.num_heads + hk * G + g) * DH + d) = v;
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * DH + d) = v;
         }
         else
         {
@@ -338,7 +362,7 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int b, int hk
     {
         // global_atomic_inc with wrap value splits - 1: the arrival that finds splits - 1 is the last one, and its
         // own increment puts the word back to zero for the next launch (arrival_ring.hip)
-        dec_gu32* word = (dec_gu32*) (p.arrivals + ((size_t) b * p.num_kv_heads + hk) * ARRIVAL_WORD_STRIDE);
+        dec_gu32* word = (dec_gu32*) (p.arrivals + (size_t) group * ARRIVAL_WORD_STRIDE);
         const uint32_t seen = __builtin_amdgcn_atomic_inc32(word, (uint32_t) (p.splits - 1), __ATOMIC_RELAXED, "agent");
         *last = seen == (uint32_t) (p.splits - 1);
     }
@@ -380,7 +404,7 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int b, int hk
             }
             const float inv = 1.f / (ll + 1e-6f); // decoderMaskedMultiheadAttentionTemplate.h:2771-2777
             const uint2 w = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t) b * p.num_heads + hk * G + g) * DH + d) = w;
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * DH + d) = w;
         }
         MQ_STAMP(p, 9);
         return;
@@ -432,7 +456,7 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int b, int hk
         // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2771-2777)
         const float inv = 1.f / (l_s[g] + 1e-6f);
         const uint2 v = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + ((size_t) b * p.num_heads + hk * G + g) * DH + d) = v;
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * DH + d) = v;
     }
 }
 

@@ -1042,6 +1042,14 @@ struct GPTAttentionPlugin : PluginBase
             mi355q_decode_attention_params p = baseParams(batch, max_blocks, max_blocks * f.tokens_per_block);
             gen = mi355q_decode_attention_workspace_size(&p);
         }
+        else if (f.use_cache)
+        {
+            const auto& kv = in[getIdx(PAST_KEY_VALUE)].dims; // [B, 2, Hkv, S, Dh]
+            mi355q_decode_attention_params p = baseParams(batch, 1, kv.d[3]);
+            p.kv_linear_buffer = reinterpret_cast<const void*>(uintptr_t(256)); // sizes only: marks the linear layout
+            p.linear_max_seq_len = kv.d[3];
+            gen = mi355q_decode_attention_workspace_size(&p);
+        }
         return std::max(ctx, gen);
     }
     void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc* outDesc, const void* const* inputs,
@@ -1067,20 +1075,29 @@ struct GPTAttentionPlugin : PluginBase
         if (f.cross_attention || f.is_medusa_enabled || f.unfuse_qkv_gemm || f.pos_shift_enabled)
             MQ_UNSUPPORTED("GPTAttention: cross attention / medusa / unfused qkv / pos_shift are not built");
         if (f.use_cache && !f.paged_kv_cache)
-            MQ_UNSUPPORTED("GPTAttention: only the paged KV cache (KVBlockArray) is built");
+        {
+            // the contiguous cache is output 1, aliased to the past_key_value input by the engine; copy when it is not
+            // (gptAttentionPlugin.cpp:524-537)
+            const void* past = inputs[getIdx(PAST_KEY_VALUE)];
+            if (past != outputs[1])
+            {
+                const size_t bytes = (size_t) dims_prod(outDesc[1].dims, 0, outDesc[1].dims.nbDims) * dtype_size(kvType());
+                MQ_HIP(hipMemcpyAsync(outputs[1], past, bytes, hipMemcpyDeviceToDevice, stream));
+            }
+        }
         const int hidden = qkvDims.d[hiddenDimIndex()];
         MQ_CHECK(hidden == (f.num_heads + 2 * f.num_kv_heads) * f.head_size, "qkv hidden size %d", hidden);
         const int outHidden = f.num_heads * f.head_size;
         const size_t esz = dtype_size(f.type);
-        (void) outDesc;
         if (nbContext > 0)
-            enqueueContext(0, nbContext, 0, contextTokenIdxEnd, inDesc, inputs, outputs, workspace, stream);
+            enqueueContext(0, nbContext, 0, contextTokenIdxEnd, inDesc, outDesc, inputs, outputs, workspace, stream);
         if (nbSeq - nbContext > 0)
         {
             const int tokens = f.remove_input_padding ? qkvDims.d[0] - contextTokenIdxEnd : qkvDims.d[0] * qkvDims.d[1];
-            enqueueGeneration(nbContext, nbSeq - nbContext, tokens, inDesc,
+            enqueueGeneration(nbContext, nbSeq - nbContext, tokens, inDesc, outDesc,
                 static_cast<const char*>(inputs[getIdx(QKV_TENSOR)]) + (size_t) contextTokenIdxEnd * hidden * esz,
-                static_cast<char*>(outputs[0]) + (size_t) contextTokenIdxEnd * outHidden * esz, inputs, workspace, stream);
+                static_cast<char*>(outputs[0]) + (size_t) contextTokenIdxEnd * outHidden * esz, inputs, outputs, workspace,
+                stream);
         }
     }
     // block table of this layer, first sequence seqBeg (:506-519)
@@ -1092,19 +1109,31 @@ struct GPTAttentionPlugin : PluginBase
         const int64_t layerOffset = (int64_t) f.layer_idx * bpDims.d[1] * seqStride;
         return static_cast<const int64_t*>(inputs[getIdx(KV_CACHE_BLOCK_POINTERS)]) + layerOffset + seqBeg * seqStride;
     }
-    void checkWindow(const mi355q_tensor_desc* inDesc, const void* const* inputs, int need) const
+    // the contiguous cache of sequence seqBeg onwards: output 1 = [B, 2, Hkv, S, Dh] (gptAttentionPlugin.cpp:524-529)
+    void* linearCache(const mi355q_tensor_desc* outDesc, void* const* outputs, int seqBeg, int& max_seq) const
+    {
+        const auto& d = outDesc[1].dims;
+        MQ_CHECK(d.nbDims == 5 && d.d[1] == 2 && d.d[2] == f.num_kv_heads && d.d[4] == f.head_size,
+            "present_key_value must be [batch, 2, num_kv_heads, max_seq_len, head_size]");
+        max_seq = d.d[3];
+        return static_cast<char*>(outputs[1]) + (size_t) seqBeg * dims_prod(d, 1, d.nbDims) * dtype_size(kvType());
+    }
+    // the context phase writes tokens at their own positions: a window shorter than the context (the reference then
+    // masks a sliding window and writes cyclically) and sink tokens are not built there
+    void checkContextWindow(const mi355q_tensor_desc* inDesc, const void* const* inputs, int need) const
     {
         const auto& indir = inDesc[getIdx(CACHE_INDIR)].dims;
         if (indir.d[1] != 1)
-            MQ_UNSUPPORTED("GPTAttention: beam_width %d (only 1 is built)", (int) indir.d[1]);
+            MQ_UNSUPPORTED("GPTAttention context: beam_width %d (the context phase runs with beam width 1)", (int) indir.d[1]);
         const int cyclic_window = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
         const int sink = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
         if (sink != 0 || cyclic_window < need)
-            MQ_UNSUPPORTED("GPTAttention: cyclic / sink-token cache addressing is not built (window %d, sink %d, kv length %d)",
-                cyclic_window, sink, need);
+            MQ_UNSUPPORTED("GPTAttention context: a context longer than the attention window, or sink tokens, are not built "
+                           "(window %d, sink %d, context length %d)", cyclic_window, sink, need);
     }
     void enqueueContext(int seqBeg, int nb, int tokenBeg, int nbTokens, const mi355q_tensor_desc* inDesc,
-        const void* const* inputs, void* const* outputs, void* workspace, hipStream_t stream) // enqueueSome is_context, :565-600
+        const mi355q_tensor_desc* outDesc, const void* const* inputs, void* const* outputs, void* workspace,
+        hipStream_t stream) // enqueueSome is_context, :565-600
     {
         MQ_CHECK(seqBeg == 0 && tokenBeg == 0, "context requests come first");
         if (f.mask_type != 1)
@@ -1126,9 +1155,14 @@ struct GPTAttentionPlugin : PluginBase
         mi355q_context_attention_params c = contextParams(nb, 0, max_len, nbTokens);
         if (f.use_cache)
         {
-            checkWindow(inDesc, inputs, max_len);
-            c.block_pointers = blockPointers(inDesc, inputs, seqBeg, max_blocks);
-            c.max_blocks_per_seq = max_blocks;
+            checkContextWindow(inDesc, inputs, max_len);
+            if (f.paged_kv_cache)
+            {
+                c.block_pointers = blockPointers(inDesc, inputs, seqBeg, max_blocks);
+                c.max_blocks_per_seq = max_blocks;
+            }
+            else
+                c.kv_linear_buffer = linearCache(outDesc, outputs, seqBeg, c.linear_max_seq_len);
             if (hasKvQuant())
                 c.kv_scale_orig_quant = static_cast<const float*>(inputs[getIdx(KV_CACHE_QUANTIZATION_SCALE)]);
         }
@@ -1140,17 +1174,35 @@ struct GPTAttentionPlugin : PluginBase
         c.workspace_bytes = workspace ? mi355q_context_attention_workspace_size(&c) : 0;
         context_attention(c, stream);
     }
-    void enqueueGeneration(int seqBeg, int nb, int tokens, const mi355q_tensor_desc* inDesc, const void* qkv, void* out,
-        const void* const* inputs, void* workspace, hipStream_t stream) // enqueueSome !is_context, :606-656
+    void enqueueGeneration(int seqBeg, int nb, int tokens, const mi355q_tensor_desc* inDesc,
+        const mi355q_tensor_desc* outDesc, const void* qkv, void* out, const void* const* inputs, void* const* outputs,
+        void* workspace, hipStream_t stream) // enqueueSome !is_context, :606-656
     {
         MQ_CHECK(f.use_cache, "KV-cache-less is only supported for context");
         MQ_CHECK(tokens == nb, "Only Medusa mode supports input length > 1 in the generation phase");
         const int32_t* past = static_cast<const int32_t*>(inputs[getIdx(HOST_PAST_KEY_VALUE_LENGTHS)]) + seqBeg;
         const int max_past = *std::max_element(past, past + nb);
-        checkWindow(inDesc, inputs, max_past + 1);
         int max_blocks = 0;
-        const int64_t* bp = blockPointers(inDesc, inputs, seqBeg, max_blocks);
+        const int64_t* bp = f.paged_kv_cache ? blockPointers(inDesc, inputs, seqBeg, max_blocks) : nullptr;
         mi355q_decode_attention_params p = baseParams(nb, max_blocks, max_past + 1);
+        if (!f.paged_kv_cache)
+        {
+            p.kv_linear_buffer = linearCache(outDesc, outputs, seqBeg, p.linear_max_seq_len);
+            p.max_blocks_per_seq = 1;
+        }
+        // window, sink tokens, beams (:476-489, :612-616): nb counts batch x beam rows
+        const auto& indir = inDesc[getIdx(CACHE_INDIR)].dims; // [num_requests, beam_width, max_attention_window_size]
+        p.cyclic_attention_window_size = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
+        p.sink_token_length = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
+        if (indir.d[1] > 1)
+        {
+            MQ_CHECK(nb % indir.d[1] == 0 && seqBeg % indir.d[1] == 0, "batch_beam %d (from %d) against beam_width %d", nb,
+                seqBeg, (int) indir.d[1]);
+            p.beam_width = indir.d[1];
+            p.max_attention_window_size = indir.d[2];
+            p.cache_indirection = static_cast<const int32_t*>(inputs[getIdx(CACHE_INDIR)]) + (size_t) seqBeg * indir.d[2];
+            p.input_lengths = static_cast<const int32_t*>(inputs[getIdx(CONTEXT_LENGTHS)]) + seqBeg;
+        }
         p.qkv = qkv;
         p.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
         p.out = out;

@@ -226,3 +226,40 @@ def test_c_decode_attention_agrees_with_python_oracle():
             a = oracle.decode_attention(qkv, cache, lens, H, Hkv, D, rope=rope, rot_dim=D if rope else 0, update_cache=False)
             b = oracle.decode_attention_c(qkv, cache, lens, H, Hkv, D, rope=rope)
             assert (a.float() - b.float()).abs().max().item() <= (2e-3 if dt == torch.float16 else 8e-3)
+
+
+def test_cyclic_map_values_from_the_header():
+    """CyclicMap against values worked out by hand from kvCacheUtils.h:89-94, 109-117, 291-294, 308-316."""
+    m = oracle.CyclicMap(128, 0, 64, 3)               # (3 - 1) * 64 >= 128: one more block, 128 + 64 cyclic slots
+    assert (m.bubble, m.one_more, m.cyc_len) == (0, True, 192)
+    assert [m.slot(t) for t in (0, 127, 128, 191, 192, 300)] == [0, 127, 128, 191, 0, 108]
+    m = oracle.CyclicMap(128, 4, 64, 3)               # 4 sink tokens: bubble 60, no extra block (128 < 188)
+    assert (m.bubble, m.one_more, m.cyc_len) == (60, False, 124)
+    assert [m.slot(t) for t in (0, 3, 4, 127, 128, 130)] == [0, 3, 64, 187, 64, 66]
+    m = oracle.CyclicMap(100, 10, linear=True)        # KVLinearBuffer: no bubble, window - sink cyclic slots
+    assert (m.bubble, m.one_more, m.cyc_len) == (0, False, 90)
+    assert [m.slot(t) for t in (9, 10, 99, 100, 190)] == [9, 10, 99, 10, 10]
+
+
+def test_decode_attention_slots_is_decode_attention_without_a_window():
+    """With window = capacity, no sink tokens and one beam the slot-space restatement must reproduce decode_attention
+    bit for bit (same arithmetic, identity addressing)."""
+    torch.manual_seed(1)
+    B, Hq, Hkv, D, tpb, lens = 2, 4, 2, 64, 16, [9, 40]
+    cache = oracle.PagedKVCache(B, Hkv, D, 64, tpb, torch.float16)
+    slots = torch.zeros(B, 2, Hkv, 64, D, dtype=torch.float16)
+    for b in range(B):
+        for t in range(lens[b] - 1):
+            for kv in range(2):
+                for h in range(Hkv):
+                    v = (torch.randn(D) * 0.5).half()
+                    cache.write(b, kv, h, t, v)
+                    slots[b, kv, h, t] = v
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D).half()
+    a = oracle.decode_attention(qkv, cache, lens, Hq, Hkv, D, rope="neox", rot_dim=D)
+    m = oracle.CyclicMap(64, 0, tpb, 4)
+    b_ = oracle.decode_attention_slots(qkv, slots, lens, Hq, Hkv, D, m, rope="neox", rot_dim=D)
+    assert torch.equal(a, b_)
+    for b in range(B):
+        for h in range(Hkv):
+            assert torch.equal(cache.gather(b, 0, h, lens[b]), slots[b, 0, h, :lens[b]])
