@@ -193,6 +193,13 @@ extern "C"
         void* workspace;       /* smoothed activations (m*k, 256-B aligned) + split-K slabs; may be NULL
                                   when act_scale is NULL (split-K is then skipped) */
         size_t workspace_bytes;
+        /* W4A8-AWQ (quant_algo bit FP8_ALPHA, weightOnlyGroupwiseQuantMatmulPlugin.cpp:148-168, 376-418; all zero / NULL
+         * = the plain W4A16 / W8A16 GEMM): the activation, after the pre-quant scale, is rounded through OCP e4m3
+         * (apply_per_channel_scale<T, __nv_fp8_e4m3>, preQuantScaleKernel.cu:26-79) and the result is
+         * out = alpha * (sum_k a8 * w) + bias.  alpha is read on the device (the reference copies it to the host with a
+         * blocking cudaMemcpy, :377-380).  The workspace must hold the m * k converted activations. */
+        const float* alpha;    /* device [1] or NULL */
+        int32_t act_fp8;       /* 0 / 1 */
     } mi355q_weight_only_params;
     /* CutlassFpAIntBGemmRunner::getWorkspaceSize + the plugin's smoothed-activation area
      * (weightOnlyGroupwiseQuantMatmulPlugin.cpp:330-332) */

@@ -195,13 +195,21 @@ def matmul_16(a, w):
     return torch.from_numpy(out)
 
 
-def woq_groupwise_matmul(act, pre_quant_scale, q_unpacked, scale, zero, bias, group_size, dequant="fma"):
+def woq_groupwise_matmul(act, pre_quant_scale, q_unpacked, scale, zero, bias, group_size, dequant="fma", alpha=None,
+                         act_fp8=False):
     """Reference result of WeightOnlyGroupwiseQuantMatmul (test_weight_only_groupwise_quant_matmul.py
     :186-210, _utils.py:63-67): (act * pre) @ (q*scale + zero) + bias, output in the act dtype.
+    W4A8-AWQ (act_fp8, alpha; weightOnlyGroupwiseQuantMatmulPlugin.cpp:376-418, the test's :202-210): the smoothed
+    activation is rounded through OCP e4m3 (apply_per_channel_scale<T, __nv_fp8_e4m3>: static_cast of the T-rounded
+    product, saturating) and the accumulator is multiplied by alpha before the bias is added.
     Returns (out16, out_f32_before_cast)."""
     w = (dequant_fma if dequant == "fma" else dequant_torch)(q_unpacked, scale, zero, group_size)
     a = act if pre_quant_scale is None else apply_per_channel_scale(act, pre_quant_scale)
+    if act_fp8:
+        a = a.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(act.dtype)
     ref = matmul_16(a.reshape(-1, a.shape[-1]), w)
+    if alpha is not None:
+        ref = ref * np.float32(float(alpha))
     if bias is not None and bias.numel():
         ref = ref + bias.float().reshape(1, -1)
     return ref.to(act.dtype), ref

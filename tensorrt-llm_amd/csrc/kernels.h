@@ -47,12 +47,17 @@ struct WoqArgsHost
     int m, n, k, group, group_shift, ktiles;
     bool bf16, int4;
     float* slabs; // fp32 [ksplit][m][n] workspace, or null (then no split-K)
+    const float* alpha; // device [1] or null
 };
 bool woq_prefill_supported(int m, int n, int k);
 int woq_prefill_ksplit(int m, int n, int k, int weight_type);
-void woq_splitk_reduce(const float* slabs, const void* bias, void* out, int m, int n, int ksplit, bool bf16, hipStream_t stream);
+void woq_splitk_reduce(const float* slabs, const void* bias, const float* alpha, void* out, int m, int n, int ksplit,
+    bool bf16, hipStream_t stream);
 void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream);
 void apply_per_channel_scale(
+    void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream);
+// the W4A8 form: T(e4m3(T(act * scale))), scale may be null
+void apply_per_channel_scale_fp8(
     void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream);
 // plugins.cpp: smoothing (if act_scale) + GEMM, carving p.workspace
 void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stream);

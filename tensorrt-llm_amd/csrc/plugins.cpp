@@ -176,8 +176,8 @@ struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
         mZerosInputIdx = (quant_algo & ZERO) ? mScalesInputIdx + 1 : mScalesInputIdx;
         mBiasesInputIdx = (quant_algo & BIAS) ? mZerosInputIdx + 1 : mZerosInputIdx;
         mAlphaInputIdx = (quant_algo & FP8_ALPHA) ? mBiasesInputIdx + 1 : mBiasesInputIdx;
-        if (quant_algo & FP8_ALPHA) // :148-154: Hopper-only in the reference, not built here either
-            MQ_UNSUPPORTED("W4A(fp)8 kernel is unsupported on this architecture!");
+        // FP8_ALPHA (W4A8-AWQ) is Hopper-only in the reference (:148-154); built here: e4m3-rounded activations through
+        // the W4A16 kernels (every e4m3 value is exact in fp16 / bf16), alpha applied in their epilogues
         if (mType != MI355Q_HALF && mType != MI355Q_BF16)
             MQ_UNSUPPORTED("Unsupported data type");
         MQ_CHECK(group_size > 0 && group_size % 64 == 0, "group_size must be a multiple of 64 (64 or 128), got %d",
@@ -203,6 +203,8 @@ struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
     bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int, int) const override // :283-308
     {
         MQ_CHECK(pos < mAlphaInputIdx + 2, "pos");
+        if ((mQuantAlgo & FP8_ALPHA) && pos == mAlphaInputIdx)
+            return io[pos].type == MI355Q_FLOAT && io[pos].format == 0; // :293-296
         return io[pos].type == mType && io[pos].format == 0;
     }
     int getOutputDataType(int idx, const int32_t*, int) const override
@@ -236,6 +238,11 @@ struct WeightOnlyGroupwiseQuantMatmulPlugin : PluginBase
         p.zeros = (mQuantAlgo & ZERO) ? inputs[mZerosInputIdx] : nullptr;
         p.bias = (mQuantAlgo & BIAS) ? inputs[mBiasesInputIdx] : nullptr;
         p.act_scale = (mQuantAlgo & PRE_QUANT_SCALE) ? inputs[mPreQuantScaleInputIdx] : nullptr;
+        if (mQuantAlgo & FP8_ALPHA)
+        {
+            p.alpha = static_cast<const float*>(inputs[mAlphaInputIdx]);
+            p.act_fp8 = 1;
+        }
         p.in = inputs[0];
         p.out = outputs[0];
         p.m = m;
@@ -1421,7 +1428,20 @@ void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stre
     mi355q_weight_only_params q = p;
     char* ws = static_cast<char*>(p.workspace);
     size_t ws_bytes = p.workspace_bytes;
-    if (p.act_scale && !woq_gemm_fuses_act_scale(p.m, p.n, p.k))
+    if (p.act_fp8)
+    {
+        // W4A8-AWQ (:382-418 with T_out = __nv_fp8_e4m3): smoothing and the e4m3 rounding in one pass, always through
+        // the workspace (the decode kernels' fused smoothing cannot round through e4m3)
+        const size_t act_bytes = align_up((size_t) p.m * p.k * 2, 256);
+        MQ_CHECK(ws && ws_bytes >= act_bytes, "workspace too small for the fp8-rounded activations (%zu < %zu)", ws_bytes,
+            act_bytes);
+        apply_per_channel_scale_fp8(ws, p.in, p.act_scale, p.m, p.k, p.act_type, stream);
+        q.in = ws;
+        q.act_scale = nullptr;
+        ws += act_bytes;
+        ws_bytes -= act_bytes;
+    }
+    else if (p.act_scale && !woq_gemm_fuses_act_scale(p.m, p.n, p.k))
     {
         // weightOnlyGroupwiseQuantMatmulPlugin.cpp:382-418: smoothed activations go to the workspace (the decode
         // kernel, m <= 32, applies the scale while it stages the rows instead: one launch less)

@@ -22,6 +22,7 @@ struct WoqArgs
     const uint16_t* act;
     const uint16_t* act_scale; // per-channel pre-quant scale [k] applied while the decode kernel stages the rows, or null
     const uint16_t* bias;
+    const float* alpha; // device [1] or null: out = alpha * acc + bias (the W4A8 alpha, fpA_intB groupwise gemm overload)
     uint16_t* out;
     float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1
     int m, n, k;

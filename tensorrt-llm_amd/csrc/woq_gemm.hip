@@ -399,6 +399,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
             // this wave owns the n-block: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
             const int on = lane & 15;
             const float bias = (a.ksplit == 1 && a.bias) ? T16<T>::to_float(a.bias[nb * 16 + on]) : 0.f;
+            const float alpha = (a.ksplit == 1 && a.alpha) ? a.alpha[0] : 1.f;
 #pragma unroll
             for (int mc = 0; mc < MC; ++mc)
             {
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
                     {
                         const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
                         if (a.ksplit == 1)
-                            a.out[oi] = T16<T>::from_float(acc[mc][r] + bias);
+                            a.out[oi] = T16<T>::from_float(acc[mc][r] * alpha + bias);
                         else
                             a.slabs[(size_t) blockIdx.z * a.m * a.n + oi] = acc[mc][r];
                     }
@@ -453,6 +454,8 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
                 const size_t oi = (size_t) (m0 + om) * a.n + nb * 16 + on;
                 if (a.ksplit == 1)
                 {
+                    if (a.alpha)
+                        v *= a.alpha[0];
                     if (a.bias)
                         v += T16<T>::to_float(a.bias[nb * 16 + on]);
                     a.out[oi] = T16<T>::from_float(v);
@@ -488,7 +491,8 @@ __global__ __launch_bounds__(NWAVES * 64) void woq_gemv_kernel(WoqArgs a)
 }
 
 template <typename T>
-__global__ void woq_splitk_reduce_kernel(const float* slabs, const uint16_t* bias, uint16_t* out, int m, int n, int ksplit)
+__global__ void woq_splitk_reduce_kernel(
+    const float* slabs, const uint16_t* bias, const float* alpha, uint16_t* out, int m, int n, int ksplit)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t) m * n)
@@ -496,6 +500,8 @@ __global__ void woq_splitk_reduce_kernel(const float* slabs, const uint16_t* bia
     float v = 0.f;
     for (int s = 0; s < ksplit; ++s)
         v += slabs[(size_t) s * m * n + i];
+    if (alpha)
+        v *= alpha[0];
     if (bias)
         v += T16<T>::to_float(bias[i % n]);
     out[i] = T16<T>::from_float(v);
@@ -554,7 +560,10 @@ __global__ void woq_dequant_kernel(WoqArgs a)
     }
 }
 
-template <typename T>
+// FP8: the W4A8 form (apply_per_channel_scale<T_in, __nv_fp8_e4m3>, preQuantScaleKernel.cu:26-79): the T-rounded
+// product is converted to OCP e4m3 (round to nearest even, saturating); stored here as the same value in T (every
+// e4m3 value is exact in fp16 and bf16), which is what the GEMM kernels read.  scale may be null then (no smoothing).
+template <typename T, bool FP8 = false>
 __global__ void per_channel_scale_kernel(uint16_t* out, const uint16_t* act, const uint16_t* scale, int rows, int cols)
 {
     // 8 elements (16 B) per thread
@@ -563,14 +572,23 @@ __global__ void per_channel_scale_kernel(uint16_t* out, const uint16_t* act, con
         return;
     const int c = (int) (i % cols);
     const uint4 av = *reinterpret_cast<const uint4*>(act + i);
-    const uint4 sv = *reinterpret_cast<const uint4*>(scale + c);
+    const uint32_t one2 = pack2<T>(1.f, 1.f);
+    const uint4 sv = scale ? *reinterpret_cast<const uint4*>(scale + c) : make_uint4(one2, one2, one2, one2);
     const uint32_t* ap = reinterpret_cast<const uint32_t*>(&av);
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(&sv);
     uint4 r;
     uint32_t* rp = reinterpret_cast<uint32_t*>(&r);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
+    {
         rp[j] = pack2<T>(T16<T>::lo(ap[j]) * T16<T>::lo(sp[j]), T16<T>::hi(ap[j]) * T16<T>::hi(sp[j]));
+        if constexpr (FP8)
+        {
+            const float lo = fminf(fmaxf(T16<T>::lo(rp[j]), -448.f), 448.f), hi = fminf(fmaxf(T16<T>::hi(rp[j]), -448.f), 448.f);
+            const int q = __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, 0, false);
+            rp[j] = pack2<T>(__builtin_amdgcn_cvt_f32_fp8(q, 0), __builtin_amdgcn_cvt_f32_fp8(q, 1));
+        }
+    }
     *reinterpret_cast<uint4*>(out + i) = r;
 }
 
@@ -591,6 +609,7 @@ WoqArgs make_args(const mi355q_weight_only_params& p)
     a.zeros = reinterpret_cast<const uint16_t*>(p.zeros);
     a.act = reinterpret_cast<const uint16_t*>(p.in);
     a.bias = reinterpret_cast<const uint16_t*>(p.bias);
+    a.alpha = p.alpha;
     a.out = reinterpret_cast<uint16_t*>(p.out);
     a.m = p.m;
     a.n = p.n;
@@ -756,7 +775,7 @@ void launch_gemv(const WoqArgs& a, hipStream_t stream)
     {
         const size_t total = (size_t) a.m * a.n;
         hipLaunchKernelGGL((woq_splitk_reduce_kernel<T>), dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream,
-            a.slabs, a.bias, a.out, a.m, a.n, a.ksplit);
+            a.slabs, a.bias, a.alpha, a.out, a.m, a.n, a.ksplit);
     }
 }
 
@@ -812,16 +831,17 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
     return best;
 }
 
-void woq_splitk_reduce(const float* slabs, const void* bias, void* out, int m, int n, int ksplit, bool bf16, hipStream_t stream)
+void woq_splitk_reduce(const float* slabs, const void* bias, const float* alpha, void* out, int m, int n, int ksplit,
+    bool bf16, hipStream_t stream)
 {
     const size_t total = (size_t) m * n;
     const dim3 grid((unsigned) ((total + 255) / 256));
     if (bf16)
         hipLaunchKernelGGL((woq_splitk_reduce_kernel<bf16_t>), grid, dim3(256), 0, stream, slabs,
-            (const uint16_t*) bias, (uint16_t*) out, m, n, ksplit);
+            (const uint16_t*) bias, alpha, (uint16_t*) out, m, n, ksplit);
     else
         hipLaunchKernelGGL((woq_splitk_reduce_kernel<f16_t>), grid, dim3(256), 0, stream, slabs,
-            (const uint16_t*) bias, (uint16_t*) out, m, n, ksplit);
+            (const uint16_t*) bias, alpha, (uint16_t*) out, m, n, ksplit);
 }
 
 // m <= 32 (or shapes the prefill GEMM does not take) run the decode kernel, which applies the pre-quant scale itself
@@ -846,10 +866,10 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
         const size_t need = (size_t) ks * p.m * p.n * sizeof(float);
         float* slabs = (ks > 1 && workspace && workspace_bytes >= need) ? reinterpret_cast<float*>(workspace) : nullptr;
         WoqArgsHost h{a.qweight, a.scales, a.zeros, a.act, a.bias, a.out, a.m, a.n, a.k, a.group, a.group_shift, a.ktiles,
-            p.act_type == MI355Q_BF16, p.weight_type == MI355Q_WEIGHT_INT4, slabs};
+            p.act_type == MI355Q_BF16, p.weight_type == MI355Q_WEIGHT_INT4, slabs, a.alpha};
         weight_only_prefill_gemm(h, stream);
         if (slabs)
-            woq_splitk_reduce(slabs, p.bias, p.out, p.m, p.n, ks, p.act_type == MI355Q_BF16, stream);
+            woq_splitk_reduce(slabs, p.bias, p.alpha, p.out, p.m, p.n, ks, p.act_type == MI355Q_BF16, stream);
         MQ_HIP(hipGetLastError());
         return;
     }
@@ -880,6 +900,24 @@ void weight_only_dequantize(const mi355q_weight_only_params& p, hipStream_t stre
 {
     WoqArgs a = make_args(p);
     MQ_DISPATCH_WOQ(launch_dequant, p, a, stream);
+    MQ_HIP(hipGetLastError());
+}
+
+void apply_per_channel_scale_fp8(void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream)
+{
+    MQ_CHECK(out && act, "null tensor");
+    MQ_CHECK(act_type == MI355Q_HALF || act_type == MI355Q_BF16, "Unsupported data type %d", act_type);
+    MQ_CHECK(cols % 8 == 0, "cols must be a multiple of 8 (preQuantScaleKernel.cu:86-89), got %d", cols);
+    if (rows == 0)
+        return;
+    const size_t vecs = (size_t) rows * cols / 8;
+    dim3 grid((unsigned) ((vecs + 255) / 256));
+    if (act_type == MI355Q_BF16)
+        hipLaunchKernelGGL((per_channel_scale_kernel<bf16_t, true>), grid, dim3(256), 0, stream, (uint16_t*) out,
+            (const uint16_t*) act, (const uint16_t*) scale, rows, cols);
+    else
+        hipLaunchKernelGGL((per_channel_scale_kernel<f16_t, true>), grid, dim3(256), 0, stream, (uint16_t*) out,
+            (const uint16_t*) act, (const uint16_t*) scale, rows, cols);
     MQ_HIP(hipGetLastError());
 }
 

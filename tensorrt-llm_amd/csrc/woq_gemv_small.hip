@@ -482,6 +482,8 @@ __global__ __launch_bounds__(LW * 64) void woq_gemv_light_kernel(LightArgs p)
     {
         if (mine)
         {
+            if (a.alpha)
+                v *= a.alpha[0];
             if (a.bias)
                 v += T16<T>::to_float(a.bias[nb * 16 + on]);
             a.out[oi] = T16<T>::from_float(v);
@@ -521,6 +523,8 @@ __global__ __launch_bounds__(LW * 64) void woq_gemv_light_kernel(LightArgs p)
             for (int j = 0; j < 8; ++j)
                 sum += x[j];
         }
+        if (a.alpha)
+            sum *= a.alpha[0];
         if (a.bias)
             sum += T16<T>::to_float(a.bias[nb * 16 + on]);
         a.out[oi] = T16<T>::from_float(sum);
@@ -623,6 +627,7 @@ void weight_only_gemv_light(const mi355q_weight_only_params& p, LightPlan pl, vo
     a.act = reinterpret_cast<const uint16_t*>(p.in);
     a.act_scale = reinterpret_cast<const uint16_t*>(p.act_scale);
     a.bias = reinterpret_cast<const uint16_t*>(p.bias);
+    a.alpha = p.alpha;
     a.out = reinterpret_cast<uint16_t*>(p.out);
     a.m = p.m, a.n = p.n, a.k = p.k;
     a.group = group;

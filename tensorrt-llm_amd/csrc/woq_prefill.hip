@@ -315,6 +315,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     {
         const int n = (nb0 + b) * 16 + en;
         float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        const float alpha = (a.alpha && a.ksplit == 1) ? a.alpha[0] : 1.f; // out = alpha * acc + bias
         if (a.bias && a.ksplit == 1)
         {
             const uint2 bv = *reinterpret_cast<const uint2*>(a.bias + n);
@@ -332,8 +333,8 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
             const size_t oi = (size_t) m * a.n + n;
             if (a.ksplit == 1)
                 *reinterpret_cast<uint2*>(a.out + oi)
-                    = make_uint2(pack2<T>(acc[b][j][0] + bias[0], acc[b][j][1] + bias[1]),
-                        pack2<T>(acc[b][j][2] + bias[2], acc[b][j][3] + bias[3]));
+                    = make_uint2(pack2<T>(acc[b][j][0] * alpha + bias[0], acc[b][j][1] * alpha + bias[1]),
+                        pack2<T>(acc[b][j][2] * alpha + bias[2], acc[b][j][3] * alpha + bias[3]));
             else
                 *reinterpret_cast<float4*>(a.slabs + (size_t) blockIdx.y * a.m * a.n + oi)
                     = make_float4(acc[b][j][0], acc[b][j][1], acc[b][j][2], acc[b][j][3]);
@@ -394,6 +395,7 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
     a.zeros = h.zeros;
     a.act = h.act;
     a.bias = h.bias;
+    a.alpha = h.alpha;
     a.out = h.out;
     a.m = h.m;
     a.n = h.n;

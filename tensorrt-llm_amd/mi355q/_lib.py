@@ -60,6 +60,7 @@ class WeightOnlyParams(C.Structure):
         ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("group_size", C.c_int32),
         ("weight_type", C.c_int32), ("act_type", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("alpha", C.c_void_p), ("act_fp8", C.c_int32),
     ]
 
 

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DT = {"float16": torch.float16, "bfloat16": torch.bfloat16}
 
 
-def _groupwise_case(m, n, k, dtype_str, has_pre_quant, has_zero, has_bias, group_size, dev):
+def _groupwise_case(m, n, k, dtype_str, has_pre_quant, has_zero, has_bias, group_size, dev, use_w4a8_awq=False):
     """_woq_groupwise_matmul (test_weight_only_groupwise_quant_matmul.py:129-210) with our plugin."""
     torch.manual_seed(0)
     dt = DT[dtype_str]
@@ -33,14 +33,26 @@ def _groupwise_case(m, n, k, dtype_str, has_pre_quant, has_zero, has_bias, group
     ref_q_weight = F.unpack_int4_packed_tensor_to_int8(unprocessed_weight)
     assert (ref_q_weight.numpy() == oracle.unpack_int4_packed_tensor_to_int8(unprocessed_weight.numpy())).all()
     cuda_q_weight = F.preprocess_weights_for_mixed_gemm(unprocessed_weight, torch.quint4x2).view(dt)
-    quant_algo = has_pre_quant * F.PRE_QUANT_SCALE + has_zero * F.ZERO + has_bias * F.BIAS
+    fp8_alpha = torch.rand(1, dtype=torch.float32) if use_w4a8_awq else None  # :156-157
+    quant_algo = use_w4a8_awq * F.FP8_ALPHA + has_pre_quant * F.PRE_QUANT_SCALE + has_zero * F.ZERO + has_bias * F.BIAS
 
     d = lambda t: None if t is None else t.to(dev)
     out = F.weight_only_groupwise_quant_matmul(d(activation), d(pre_quant_scale), d(cuda_q_weight), d(scale), d(zero),
-                                               d(bias), None, quant_algo, group_size, dtype_str)
+                                               d(bias), d(fp8_alpha), quant_algo, group_size, dtype_str)
     torch.cuda.synchronize()
     ref16, ref32 = oracle.woq_groupwise_matmul(activation, pre_quant_scale if has_pre_quant else None,
-                                               ref_q_weight.numpy(), scale, zero, bias, group_size)
+                                               ref_q_weight.numpy(), scale, zero, bias, group_size,
+                                               alpha=fp8_alpha, act_fp8=use_w4a8_awq)
+    if use_w4a8_awq:
+        # the reference's own gate for this mode (:202-210): the UN-rounded activation x alpha x pre-quant scale
+        # against the plugin, woq_assert_near_eq(ref, output, 2) -- wTypeId 2 = the int4 tolerance
+        a = activation.float() * fp8_alpha
+        if has_pre_quant:
+            a = a * pre_quant_scale.float()
+        w = oracle.dequant_fma(ref_q_weight.numpy(), scale, zero, group_size).float()
+        gt = a.double() @ w.double() + (bias.double() if has_bias else 0.0)
+        atol_ref = gt.abs().max().item() / (1 << 3) * 1.5 * (3.0 if dt == torch.bfloat16 else 1.0)
+        assert (out.cpu().double() - gt).abs().max().item() <= atol_ref
     atol = oracle.woq_tolerance(ref16, oracle.INT4_W)
     torch.testing.assert_close(out.cpu().float(), ref16.float(), atol=atol, rtol=1e-7)
     # much tighter than the reference gate: the same dequantised weights, fp32 accumulation
@@ -70,6 +82,20 @@ GROUPWISE_GRID = [
 @pytest.mark.parametrize("m,n,k,pre,zero,bias,gs", GROUPWISE_GRID)
 def test_weight_only_groupwise_quant_matmul(cuda, dtype_str, m, n, k, pre, zero, bias, gs):
     _groupwise_case(m, n, k, dtype_str, pre, zero, bias, gs, cuda)
+
+
+# W4A8-AWQ (FP8_ALPHA): the reference's Hopper-only grid (:318-330, :360-372 at the group sizes built here) plus the
+# decode and mid-size row counts, both activation types
+W4A8_GRID = [(256, 2048, 1024, True, False, False, 128), (32, 1024, 128, True, True, True, 128),
+             (32, 2048, 1024, True, False, True, 128), (64, 2048, 2048, True, False, False, 128),
+             (1, 4096, 4096, True, True, False, 128), (8, 1280, 8192, True, True, True, 128),
+             (16, 1024, 512, False, True, True, 64), (100, 1024, 1024, False, False, True, 64)]
+
+
+@pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
+@pytest.mark.parametrize("m,n,k,pre,zero,bias,gs", W4A8_GRID)
+def test_w4a8_awq_groupwise_quant_matmul(cuda, dtype_str, m, n, k, pre, zero, bias, gs):
+    _groupwise_case(m, n, k, dtype_str, pre, zero, bias, gs, cuda, use_w4a8_awq=True)
 
 
 @pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])

@@ -148,10 +148,19 @@ def test_groupwise_plugin_input_compaction_and_shapes():
         assert p.clone().serialize() == blob
 
 
-def test_groupwise_plugin_rejects_w4a8_and_fp32():
-    with pytest.raises(L.Mi355qError, match="unsupported"):
-        Plugin("WeightOnlyGroupwiseQuantMatmul", [("type_id", L.HALF, L.FIELD_INT32), ("quant_algo", 8, L.FIELD_INT32),
+def test_groupwise_plugin_accepts_w4a8_and_rejects_fp32():
+    # FP8_ALPHA (W4A8-AWQ) is built: one more input (alpha, float32) after the optional bias (:138-146, :293-296)
+    p = Plugin("WeightOnlyGroupwiseQuantMatmul", [("type_id", L.HALF, L.FIELD_INT32), ("quant_algo", 8 + 4 + 1, L.FIELD_INT32),
                                                    ("group_size", 128, L.FIELD_INT32)])
+    descs = [L.TensorDesc() for _ in range(7)]
+    for d_ in descs:
+        d_.type, d_.format = L.HALF, 0
+    descs[5].type = L.FLOAT  # activation, pre_quant_scale, weights, scales, bias, ALPHA, output
+    arr = (L.TensorDesc * 7)(*descs)
+    assert p.supports_format_combination(5, arr, 6, 1)
+    descs[5].type = L.HALF
+    arr = (L.TensorDesc * 7)(*descs)
+    assert not p.supports_format_combination(5, arr, 6, 1)
     with pytest.raises(L.Mi355qError, match="Unsupported data type"):
         Plugin("WeightOnlyGroupwiseQuantMatmul", [("type_id", L.FLOAT, L.FIELD_INT32), ("quant_algo", 0, L.FIELD_INT32),
                                                    ("group_size", 128, L.FIELD_INT32)])

@@ -263,3 +263,16 @@ def test_decode_attention_slots_is_decode_attention_without_a_window():
     for b in range(B):
         for h in range(Hkv):
             assert torch.equal(cache.gather(b, 0, h, lens[b]), slots[b, 0, h, :lens[b]])
+
+
+def test_w4a8_awq_oracle_known_answers():
+    """W4A8-AWQ restatement on values worked out by hand: e4m3 rounding of the smoothed activation (1.0625 -> 1.0,
+    1.1875 -> 1.25 (tie to even mantissa), 500 -> 448 saturated), alpha before the bias."""
+    act = torch.tensor([[1.0625, 1.1875, 500.0, -3.0] + [0.0] * 60], dtype=torch.float16)
+    q = np.zeros((64, 16), np.int8)
+    q[0, 0], q[1, 0], q[2, 0], q[3, 0] = 1, 1, 1, 2
+    scale = torch.ones(1, 16, dtype=torch.float16)
+    bias = torch.full((1, 16), 0.5, dtype=torch.float16)
+    out16, out32 = oracle.woq_groupwise_matmul(act, None, q, scale, None, bias, 64, alpha=torch.tensor([0.5]), act_fp8=True)
+    assert out32[0, 0].item() == (1.0 + 1.25 + 448.0 - 6.0) * 0.5 + 0.5
+    assert out32[0, 1].item() == 0.5
