@@ -241,6 +241,30 @@ def bench_fp8_gemm(dev, steps, m=4096, n=14336, k=4096):
             "frac_of_fp8_peak": ops / (dev_s / steps) / 1e12 / INT8_PEAK_TOPS}
 
 
+def bench_moe_gemm(dev, steps, tokens=64, top_k=2, experts=8, n=28672, k=4096):
+    """§8(f) rank 4: the expert GEMMs of a Mixtral-8x7B MoE layer (w1|w3 fused: 4096 -> 2 x 14336) with int4
+    weight-only experts, one grouped launch; rows spread evenly over the experts (synthetic routing)."""
+    from mi355q import functional as F
+    from mi355q import _lib as L
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    rows = tokens * top_k
+    per = [rows // experts + (1 if e < rows % experts else 0) for e in range(experts)]
+    cum = torch.tensor(per, dtype=torch.int64).cumsum(0).to(dev)
+    w = torch.randint(-128, 128, (experts, k, n // 2), dtype=torch.int8, device=dev)  # preprocessed bytes: any pattern
+    sc = (torch.rand(experts, n, device=dev) * 0.01).to(dt)
+    a = (torch.randn(rows, k, device=dev) * 0.5).to(dt)
+    _, dev_s = time_steps(lambda: F.moe_gemm_bias_act(a, w, sc, None, cum, L.WEIGHT_INT4), steps, 2, lambda: None)
+    t = dev_s / steps
+    flops = 2.0 * rows * n * k
+    wbytes = experts * n * k // 2 + experts * n * 2
+    algo = wbytes + rows * k * 2 + rows * n * 2
+    return {"tokens": tokens, "top_k": top_k, "experts": experts, "rows": rows, "n": n, "k": k, "weights": "int4 per-column",
+            "us_per_call": t * 1e6, "TFLOPS": flops / t / 1e12, "GBps": algo / t / 1e9,
+            "frac_of_8TBps": algo / t / 1e9 / HBM_PEAK_GBS, "frac_of_bf16_peak": flops / t / 1e12 / (INT8_PEAK_TOPS / 2),
+            "algorithmic_bytes": algo}
+
+
 def bench_prefill_w4a16(dev, steps, m=4096, n=11008, k=4096, g=128):
     """a4: prefill-M W4A16 AWQ GEMM (dequant in registers -> bf16 MFMA), Llama-2-7B gate/up shape."""
     from mi355q import _lib as L
@@ -627,6 +651,7 @@ def main():
                 sec["context_attention"] = [bench_context_attention(dev, 10),
                                             bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8")]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
+                sec["moe_w4_grouped_gemm"] = [bench_moe_gemm(dev, 10, tokens=64), bench_moe_gemm(dev, 10, tokens=4096)]
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)
             res["secondary"] = sec

@@ -209,6 +209,27 @@ extern "C"
      * (the reference tests do this with an identity matmul, test_weight_only_quant_matmul.py:44-53). */
     mi355q_status mi355q_weight_only_dequantize(const mi355q_weight_only_params* params, void* stream);
 
+    /* kernels/cutlass_kernels/moe_gemm/moe_gemm_kernels.h:51-58 MoeGemmRunner<T, WeightType>::moeGemmBiasAct /
+     * moeGemm with weight-only quantised experts (WeightType uint8_t / cutlass::uint4b_t: moe_gemm_kernels_*_uint{4,8}.cu):
+     * for every expert e, C[rows_e, :] = act(A[rows_e, :] x dequant(B[e]) + biases[e]), rows sorted by expert,
+     * rows_e = [total_rows_before_expert[e-1], total_rows_before_expert[e]) (inclusive cumulative counts on the
+     * device, computeTotalRowsBeforeExpert in kernels/mixtureOfExperts/moe_kernels.cu).  One launch. */
+    typedef struct
+    {
+        const void* A;             /* [total_rows, gemm_k] act dtype */
+        const void* B;             /* [num_experts] preprocessed weights (MI355Q_LAYOUT_GFX950 of each [k, n] matrix) */
+        const void* weight_scales; /* [num_experts, gemm_n] act dtype (per-column scales) */
+        const void* biases;        /* [num_experts, gemm_n] act dtype or NULL (moeGemm) */
+        void* C;                   /* [total_rows, gemm_n] act dtype */
+        const int64_t* total_rows_before_expert; /* device [num_experts] */
+        int64_t total_rows, gemm_n, gemm_k;
+        int32_t num_experts;
+        int32_t activation_type;   /* ActivationType (moe_gemm_kernels.h:27-36): 0 Gelu, 1 Relu, 2 Silu, 5 Identity */
+        int32_t weight_type;       /* MI355Q_WEIGHT_INT8 / INT4 */
+        int32_t act_type;          /* MI355Q_HALF / MI355Q_BF16 */
+    } mi355q_moe_gemm_params;
+    mi355q_status mi355q_moe_gemm_bias_act(const mi355q_moe_gemm_params* params, void* stream);
+
     /* kernels/preQuantScaleKernel.cu:26-136 apply_per_channel_scale_kernel_launcher */
     mi355q_status mi355q_apply_per_channel_scale(
         void* out, const void* act, const void* scale, int32_t rows, int32_t cols, int32_t act_type, void* stream);

@@ -224,6 +224,34 @@ def woq_matmul(act, q_unpacked, scale):
     return ref.to(act.dtype), ref
 
 
+def moe_gemm_bias_act(a, q_unpacked, scales, biases, total_rows_before_expert, activation="identity"):
+    """MoeGemmRunner::moeGemmBiasAct with weight-only experts, restated (moe_gemm_kernels.h:51-58,
+    moe_gemm_kernels_template.h:401-470): rows of `a` are sorted by expert, expert e owns rows
+    [total_rows_before_expert[e-1], total_rows_before_expert[e]); out = act(a_e @ dequant(q_e, scales_e) + bias_e) with
+    the per-column dequantisation of the weight-only GEMM (dequant_fma), fp32 epilogue rounded once to T.
+    activation: identity / relu / silu / gelu (cutlass GELU_taylor: 0.5 x (1 + tanh(0.79788456 x (1 + 0.044715 x^2)))).
+    q_unpacked: numpy int8 [E, k, n]; scales [E, n]; biases [E, n] or None.  Returns (out16, out_f32)."""
+    E, K, N = q_unpacked.shape
+    out = torch.zeros(a.shape[0], N, dtype=torch.float32)
+    r0 = 0
+    for e in range(E):
+        r1 = int(total_rows_before_expert[e])
+        if r1 > r0:
+            w = dequant_fma(q_unpacked[e], scales[e].reshape(1, N), None, K)
+            ref = matmul_16(a[r0:r1], w)
+            if biases is not None:
+                ref = ref + biases[e].float().reshape(1, -1)
+            out[r0:r1] = ref
+        r0 = r1
+    if activation == "relu":
+        out = torch.relu(out)
+    elif activation == "silu":
+        out = out * torch.sigmoid(out)
+    elif activation == "gelu":
+        out = 0.5 * out * (1.0 + torch.tanh(0.7978845608028654 * out * (1.0 + 0.044715 * out * out)))
+    return out.to(a.dtype), out
+
+
 def woq_tolerance(ref, wtype, dtype=None):
     """_utils.py:99-109: atol = max|ref| * 2^-(bits-1) * 1.5 (x3 for bf16 in
     cpp/tests/kernels/weightOnly/weightOnlyKernelTest.cpp:316-328)."""

@@ -1669,6 +1669,16 @@ extern "C"
             });
     }
 
+    mi355q_status mi355q_moe_gemm_bias_act(const mi355q_moe_gemm_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                moe_weight_only_gemm(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
     mi355q_status mi355q_weight_only_dequantize(const mi355q_weight_only_params* params, void* stream)
     {
         return guarded(

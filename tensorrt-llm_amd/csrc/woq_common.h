@@ -31,7 +31,25 @@ struct WoqArgs
     int ktiles; // full k-tiles: k / KTILE
     int ksplit;
     int red_buffers; // decode kernel: cross-wave reduce buffers in rotation (2: one barrier per n-block; 1: two)
+    // grouped (MoE) form of the prefill kernel: rows sorted by expert, moe_rows[e] = rows of experts 0..e (inclusive
+    // cumulative, total_rows_before_expert of moe_kernels.cu); every expert has its own weights / scales / bias
+    const int64_t* moe_rows; // device [moe_experts] or null
+    int moe_experts;
+    size_t moe_wbytes;       // bytes of one expert's weight matrix
+    int act_fn;              // epilogue activation (ActivationType of moe_gemm_kernels.h: 0 gelu, 1 relu, 2 silu, 5 identity)
 };
+
+// moeGemmBiasAct's epilogues (cutlass_extensions/epilogue_helpers.h: LinearCombination{Relu, Silu, Generic<GELU_taylor>})
+__device__ __forceinline__ float woq_activation(float x, int fn)
+{
+    switch (fn)
+    {
+    case 0: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * x * (1.f + 0.044715f * x * x))); // GELU_taylor
+    case 1: return fmaxf(x, 0.f);
+    case 2: return x / (1.f + __expf(-x));
+    default: return x;
+    }
+}
 
 template <typename T>
 __device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);

@@ -99,7 +99,35 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
         const int q = nwg / 8, r = nwg % 8, x = bid % 8;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
     }
-    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int tn = bid / tiles_m;
+    int tm = bid % tiles_m;
+    if (a.moe_rows)
+    {
+        // grouped form: m-tile index over all experts -> (expert, its m-tile); then this workgroup is an ordinary tile
+        // of that expert's GEMM.  Everything here is wave-uniform (scalar loads); tiles past the last expert's leave.
+        int64_t row0 = 0;
+        int tiles_before = 0, e = 0, rows = 0;
+        for (; e < a.moe_experts; ++e)
+        {
+            const int64_t end = a.moe_rows[e];
+            rows = (int) (end - row0);
+            const int t = (rows + TM - 1) / TM;
+            if (tm < tiles_before + t)
+                break;
+            tiles_before += t;
+            row0 = end;
+        }
+        if (e == a.moe_experts)
+            return;
+        tm -= tiles_before;
+        a.m = rows;
+        a.act += row0 * a.k;
+        a.out += row0 * a.n;
+        a.qweight += (size_t) e * a.moe_wbytes;
+        a.scales += (size_t) e * a.n;
+        if (a.bias)
+            a.bias += (size_t) e * a.n;
+    }
     const int m0 = tm * TM, n0 = tn * PF_TN;
 
     // swizzle of the 16-byte chunk index by row: 16 consecutive rows x one logical chunk -> 256 distinct bytes
@@ -333,8 +361,10 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
             const size_t oi = (size_t) m * a.n + n;
             if (a.ksplit == 1)
                 *reinterpret_cast<uint2*>(a.out + oi)
-                    = make_uint2(pack2<T>(acc[b][j][0] * alpha + bias[0], acc[b][j][1] * alpha + bias[1]),
-                        pack2<T>(acc[b][j][2] * alpha + bias[2], acc[b][j][3] * alpha + bias[3]));
+                    = make_uint2(pack2<T>(woq_activation(acc[b][j][0] * alpha + bias[0], a.act_fn),
+                                     woq_activation(acc[b][j][1] * alpha + bias[1], a.act_fn)),
+                        pack2<T>(woq_activation(acc[b][j][2] * alpha + bias[2], a.act_fn),
+                            woq_activation(acc[b][j][3] * alpha + bias[3], a.act_fn)));
             else
                 *reinterpret_cast<float4*>(a.slabs + (size_t) blockIdx.y * a.m * a.n + oi)
                     = make_float4(acc[b][j][0], acc[b][j][1], acc[b][j][2], acc[b][j][3]);
@@ -403,6 +433,7 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
     a.group = h.group;
     a.group_shift = h.group_shift;
     a.ktiles = h.ktiles;
+    a.act_fn = 5; // identity
     MQ_CHECK((uint64_t) h.m * (uint64_t) h.k * 2 < (1ull << 32),
         "activation matrix of %d x %d exceeds the prefill kernel's 32-bit byte offsets (4 GiB)", h.m, h.k);
     a.ksplit = h.slabs ? plan_prefill(h.m, h.n, h.k, h.int4 ? 4 : 8).ksplit : 1;
@@ -416,6 +447,75 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
     else if (i4) launch_prefill<f16_t, 4, false>(a, stream);
     else if (z) launch_prefill<f16_t, 8, true>(a, stream);
     else launch_prefill<f16_t, 8, false>(a, stream);
+    MQ_HIP(hipGetLastError());
+}
+
+// The expert GEMMs of a mixture-of-experts layer with weight-only quantised experts, as ONE launch
+// (MoeGemmRunner<T, uint8_t | cutlass::uint4b_t>::moeGemmBiasAct, kernels/cutlass_kernels/moe_gemm/moe_gemm_kernels.h:51-58,
+// moe_gemm_kernels_template.h:401-470; the reference runs a CUTLASS grouped GEMM whose problem sizes a kernel derives
+// from total_rows_before_expert).  Here the prefill kernel's m-tile index simply runs over all experts: a workgroup
+// scans the cumulative row counts (device memory, <= 64 scalar loads), finds its expert and is from then on a tile of
+// that expert's GEMM.  The grid is sized for the worst case sum_e ceil(rows_e / TM) <= ceil(total / TM) + experts;
+// surplus workgroups leave at once.
+void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
+{
+    if (p.total_rows <= 0)
+        return;
+    MQ_CHECK(p.A && p.B && p.weight_scales && p.C && p.total_rows_before_expert, "null tensor");
+    MQ_CHECK(p.act_type == MI355Q_HALF || p.act_type == MI355Q_BF16, "Unsupported data type %d", p.act_type);
+    MQ_CHECK(p.weight_type == MI355Q_WEIGHT_INT4 || p.weight_type == MI355Q_WEIGHT_INT8, "weight_type %d", p.weight_type);
+    MQ_CHECK(p.num_experts >= 1 && p.num_experts <= 1024, "num_experts %d", p.num_experts);
+    MQ_CHECK(p.gemm_n > 0 && p.gemm_n % 128 == 0 && p.gemm_k > 0 && p.gemm_k % 64 == 0,
+        "gemm_n must be a multiple of 128 and gemm_k of 64 (n=%lld k=%lld)", (long long) p.gemm_n, (long long) p.gemm_k);
+    MQ_CHECK(p.activation_type == 0 || p.activation_type == 1 || p.activation_type == 2 || p.activation_type == 5,
+        "activation_type %d: gelu (0), relu (1), silu (2), identity (5); the gated forms run identity here and "
+        "doGatedActivation afterwards, as in the reference (moe_kernels.cu)", p.activation_type);
+    MQ_CHECK((uint64_t) p.total_rows * (uint64_t) p.gemm_k * 2 < (1ull << 32),
+        "activation matrix of %lld x %lld exceeds the kernel's 32-bit byte offsets (4 GiB)", (long long) p.total_rows,
+        (long long) p.gemm_k);
+    const bool i4 = p.weight_type == MI355Q_WEIGHT_INT4;
+    WoqArgs a{};
+    a.qweight = static_cast<const uint8_t*>(p.B);
+    a.scales = static_cast<const uint16_t*>(p.weight_scales);
+    a.act = static_cast<const uint16_t*>(p.A);
+    a.bias = static_cast<const uint16_t*>(p.biases);
+    a.out = static_cast<uint16_t*>(p.C);
+    a.m = (int) p.total_rows;
+    a.n = (int) p.gemm_n;
+    a.k = (int) p.gemm_k;
+    a.group = a.k; // per-column scales [experts, n]
+    a.group_shift = 31;
+    a.ktiles = a.k / (i4 ? 128 : 64);
+    a.ksplit = 1;
+    a.act_fn = p.activation_type;
+    a.moe_rows = p.total_rows_before_expert;
+    a.moe_experts = p.num_experts;
+    a.moe_wbytes = (size_t) p.gemm_n * p.gemm_k * (i4 ? 1 : 2) / 2;
+    // tile height from the average rows per expert (the host does not know the split)
+    const int64_t avg = (p.total_rows + p.num_experts - 1) / p.num_experts;
+    const int mt = avg <= 32 ? 2 : (avg <= 64 ? 4 : 8);
+    const int tiles_m = (int) ((p.total_rows + mt * 16 - 1) / (mt * 16)) + p.num_experts;
+    const int tiles_n = a.n / 128;
+    const bool bf = p.act_type == MI355Q_BF16;
+#define MQ_MOE(T, WB, MTV)                                                                                             \
+    hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2>), dim3(tiles_m * tiles_n, 1), dim3(PF_WAVES * 64), 0,  \
+        stream, a, tiles_m, tiles_n)
+#define MQ_MOE_MT(T, WB)                                                                                               \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (mt == 2)                                                                                                   \
+            MQ_MOE(T, WB, 2);                                                                                          \
+        else if (mt == 4)                                                                                              \
+            MQ_MOE(T, WB, 4);                                                                                          \
+        else                                                                                                           \
+            MQ_MOE(T, WB, 8);                                                                                          \
+    } while (0)
+    if (bf && i4) MQ_MOE_MT(bf16_t, 4);
+    else if (bf) MQ_MOE_MT(bf16_t, 8);
+    else if (i4) MQ_MOE_MT(f16_t, 4);
+    else MQ_MOE_MT(f16_t, 8);
+#undef MQ_MOE_MT
+#undef MQ_MOE
     MQ_HIP(hipGetLastError());
 }
 

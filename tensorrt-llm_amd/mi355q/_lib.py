@@ -64,6 +64,15 @@ class WeightOnlyParams(C.Structure):
     ]
 
 
+class MoeGemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("weight_scales", C.c_void_p), ("biases", C.c_void_p), ("C", C.c_void_p),
+        ("total_rows_before_expert", C.c_void_p),
+        ("total_rows", C.c_int64), ("gemm_n", C.c_int64), ("gemm_k", C.c_int64),
+        ("num_experts", C.c_int32), ("activation_type", C.c_int32), ("weight_type", C.c_int32), ("act_type", C.c_int32),
+    ]
+
+
 class DecodeAttentionParams(C.Structure):
     _fields_ = [
         ("qkv", C.c_void_p), ("qkv_bias", C.c_void_p), ("out", C.c_void_p),
@@ -173,6 +182,7 @@ SYMBOLS = {
     "mi355q_layer_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mi355q_fp8_gemm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_quantize_e4m3": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "mi355q_moe_gemm_bias_act": (_i32, [C.POINTER(MoeGemmParams), _vp]),
     "mi355q_decode_attention_workspace_size": (_sz, [C.POINTER(DecodeAttentionParams)]),
     "mi355q_masked_multihead_attention": (_i32, [C.POINTER(DecodeAttentionParams), _vp]),
     "mi355q_decode_attention_static_scratch_size": (_sz, []),

@@ -129,6 +129,29 @@ def weight_only_groupwise_quant_matmul(input, pre_quant_scale, weights, scales, 
     return plg(*plug_inputs)
 
 
+ACT_GELU, ACT_RELU, ACT_SILU, ACT_SWIGLU, ACT_GEGLU, ACT_IDENTITY = range(6)  # ActivationType, moe_gemm_kernels.h:27-36
+
+
+def moe_gemm_bias_act(a, expert_weights, weight_scales, biases, total_rows_before_expert, weight_type_id,
+                      activation_type=ACT_IDENTITY):
+    """MoeGemmRunner<T, uint8 | uint4>::moeGemmBiasAct (moe_gemm_kernels.h:51-58): a [rows, k] sorted by expert,
+    expert_weights [E, ...] preprocessed per expert, weight_scales [E, n], biases [E, n] or None,
+    total_rows_before_expert int64 [E] on the device.  Returns [rows, n]."""
+    import ctypes as C
+    E, n = weight_scales.shape
+    rows, k = a.shape
+    out = torch.empty(rows, n, dtype=a.dtype, device=a.device)
+    p = L.MoeGemmParams()
+    p.A, p.B, p.weight_scales = a.data_ptr(), expert_weights.data_ptr(), weight_scales.data_ptr()
+    p.biases = biases.data_ptr() if biases is not None else None
+    p.C, p.total_rows_before_expert = out.data_ptr(), total_rows_before_expert.data_ptr()
+    p.total_rows, p.gemm_n, p.gemm_k, p.num_experts = rows, n, k, E
+    p.activation_type, p.weight_type = activation_type, weight_type_id
+    p.act_type = L.HALF if a.dtype == torch.float16 else L.BF16
+    L.check(L.lib().mi355q_moe_gemm_bias_act(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
 def weight_only_quant_matmul(input, weights, scales, weightTypeId, dtype="float16"):
     """quantization/functional.py:68-104.  weights: int8 [K, N] (int8) or [K, N/2] (packed int4)."""
     plg = Plugin("WeightOnlyQuantMatmul", [
