@@ -44,8 +44,10 @@ def gptq_to_tllm(qweight_int32, qzeros_int32, scales, tp_size=1, tp_rank=0, tp_d
 
 
 def awq_quantize_pack_preprocess(weight_kn, scale, group_size, layout=L.LAYOUT_GFX950):
-    """AWQ_quantize_pack_preprocess (:1355-1359): weight [K, N] float, scale [K/g, N]."""
-    w = weight_kn / scale.repeat_interleave(group_size, dim=0)
+    """AWQ_quantize_pack_preprocess (:1355-1359): weight [K, N], scale [K/g, N].  The division runs in the tensors' own
+    dtype (`weight /= scale...` on the checkpoint's fp16 / bf16 tensors in the reference): in fp32 a quotient can land
+    on the other side of a .5 tie and round() to a different code."""
+    w = weight_kn / scale.repeat_interleave(group_size, dim=0).to(weight_kn.dtype)
     q = torch.clamp(torch.round(w).to(torch.int8), -8, 7)
     return F.preprocess_weights_for_mixed_gemm(F.pack_int8_tensor_to_packed_int4(q), torch.quint4x2, layout)
 
@@ -53,11 +55,11 @@ def awq_quantize_pack_preprocess(weight_kn, scale, group_size, layout=L.LAYOUT_G
 def awq_to_tllm(weight_nk, amax, pre_quant_scale, group_size, dtype=torch.float16, tp_size=1, tp_rank=0, tp_dim=0,
                 layout=L.LAYOUT_GFX950):
     """get_tllm_weight_from_awq (:1361-1379).  weight_nk: [N, K] float; amax: N * K/g values; pre_quant_scale: K."""
-    weight = weight_nk.float().T.contiguous()
+    weight = weight_nk.T.contiguous()  # checkpoint dtype throughout, like the reference
     k, n = weight.shape
     weight = torch_split(weight, tp_dim, tp_size, tp_rank)
-    amax = torch_split(amax.float().reshape(n, k // group_size).T.contiguous(), tp_dim, tp_size, tp_rank)
-    pqs = pre_quant_scale.float().reshape(1, k)
+    amax = torch_split(amax.reshape(n, k // group_size).T.contiguous(), tp_dim, tp_size, tp_rank)
+    pqs = pre_quant_scale.reshape(1, k)
     if tp_dim == 0:
         pqs = torch_split(pqs, 1, tp_size, tp_rank)
     scale = amax / 8.0
@@ -69,9 +71,10 @@ def resmooth_and_get_scale(weight_kn, pre_quant_scale, avg_pre_quant_scale, grou
     """reSmooth_and_get_scale (:1381-1399): fuse q/k/v (or gate/up) that share one input: move every weight to the
     averaged pre-quant scale, then the per-group scale amax / 8.  weight [K, N]; scales [1, K]."""
     k, n = weight_kn.shape
-    w = weight_kn.float()
+    w = weight_kn.clone()  # checkpoint dtype: `weight *= ...; weight /= ...` in place in the reference (:1385-1390)
     if resmooth:
-        w = w * pre_quant_scale.reshape(k, 1).float() / avg_pre_quant_scale.reshape(k, 1).float()
+        w = w * pre_quant_scale.reshape(k, 1).to(w.dtype)
+        w = w / avg_pre_quant_scale.reshape(k, 1).to(w.dtype)
     amax = w.T.reshape(n, k // group_size, group_size).abs().amax(-1).T.contiguous()
     return w, amax / 8.0
 

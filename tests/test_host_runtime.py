@@ -146,6 +146,31 @@ def test_awq_tensors_to_plugin_tensors():
     assert sc2.shape == (k // gs, n)
 
 
+def test_awq_division_runs_in_the_checkpoint_dtype():
+    """`weight /= scale...` runs on the checkpoint's fp16 tensors in the reference (models/llama/weight.py:1355-1359): a
+    quotient that fp16 rounds onto a .5 tie gives another int4 code than the fp32 quotient would."""
+    from mi355q import checkpoint as ck
+    gs = 64
+    # w / s = 2.4996 in fp32 (-> 2), but fp16(2.4996...) = 2.5 -> round-half-even 2 ... pick a value that differs:
+    s = torch.tensor(0.1, dtype=torch.float16)
+    w16 = torch.tensor(0.35, dtype=torch.float16)      # fp16(0.35) / fp16(0.1) = 3.5003 in fp32 -> 4; in fp16 3.5 -> 4
+    cands = torch.arange(0.05, 0.75, 0.0001).to(torch.float16).unique()
+    q16 = torch.round(cands / s)
+    q32 = torch.round(cands.float() / s.float())
+    differ = cands[q16 != q32.to(torch.float16)]
+    assert differ.numel() > 0, "no fp16 / fp32 rounding difference in the probe range"
+    val = differ[0]
+    weight_nk = torch.zeros(64, gs, dtype=torch.float16)
+    weight_nk[:, 0] = val
+    amax = torch.full((64,), float(s) * 8.0, dtype=torch.float16)          # scale = amax / 8 = s
+    t = ck.awq_to_tllm(weight_nk, amax, torch.ones(gs, dtype=torch.float16), gs, layout=L.LAYOUT_ROW_MAJOR)
+    q = F.unpack_int4_packed_tensor_to_int8(t["weight"])
+    want = int(torch.clamp(torch.round(val / (amax[0] / 8.0)), -8, 7).item())        # the reference's arithmetic
+    other = int(torch.clamp(torch.round(val.float() / (amax[0].float() / 8.0)), -8, 7).item())
+    assert want != other
+    assert (q[0] == want).all(), "the quotient must be formed in fp16 like the reference"
+
+
 def test_smoothquant_checkpoint_tensors():
     """models/llama/convert.py:21-176 restated in mi355q.checkpoint: the migration leaves x @ W^T unchanged when the
     activations are divided by the same scales, and the int8 tensors + scales reproduce the fp GEMM through the
