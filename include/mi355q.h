@@ -436,6 +436,12 @@ extern "C"
      * its input into peer_comm_buffer_ptrs[rank] first (allreducePlugin.cpp:195-199); here the kernel pushes it into
      * the peers' buffers itself.  dtype MI355Q_FLOAT / HALF / BF16; strategy MI355Q_AR_ONESHOT / TWOSHOT.  Capacity:
      * one-shot ranks * roundup(bytes, 256) <= comm_buffer_bytes, two-shot 2 * bytes <= comm_buffer_bytes. */
+    /* plugins/ncclPlugin/allgatherPlugin.cpp:90-110 (ncclAllGather(in, out, size, ...)): output = the ranks' inputs back
+     * to back in rank order, `bytes_per_rank` each (a multiple of 16), through the same peer buffers and flags as the
+     * one-shot all-reduce (params as for mi355q_custom_all_reduce; ranks * roundup(bytes_per_rank, 256) must fit a comm
+     * buffer).  Push-based, one launch, bounded waits (on a timeout the output is filled with NaN bytes). */
+    mi355q_status mi355q_custom_all_gather(
+        mi355q_allreduce_params* params, const void* input, void* output, size_t bytes_per_rank, void* stream);
     mi355q_status mi355q_custom_all_reduce(mi355q_allreduce_params* params, void* data, size_t elts, int32_t dtype,
         int32_t strategy, void* stream);
     /* invokeMultiGpuBarrier (:391-394) over peer_barrier_ptrs_out */

@@ -249,6 +249,44 @@ __global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
     }
 }
 
+// ALL-GATHER (plugins/ncclPlugin/allgatherPlugin.cpp:66-84: ncclAllGather(in, out, size, ...): out = the ranks' inputs
+// back to back in rank order), on the same buffers and flags as the one-shot all-reduce: push the workgroup's byte range
+// of my shard into slot `rank` of every rank's buffer, then copy the RANKS slots of the own buffer out.
+template <int RANKS>
+__global__ __launch_bounds__(AR_THREADS) void all_gather_push_kernel(ArArgs p)
+{
+    __shared__ int failed;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0)
+        failed = 0;
+    const size_t begin = (size_t) w * p.chunk_bytes;
+    const size_t end = min(begin + p.chunk_bytes, p.total_bytes); // total_bytes = one rank's shard
+    __amdgpu_buffer_rsrc_t dst[RANKS];
+#pragma unroll
+    for (int i = 0; i < RANKS; ++i)
+        dst[i] = ar_rsrc(p.comm[i] + (size_t) p.rank * p.slot_bytes, p.total_bytes);
+    const __amdgpu_buffer_rsrc_t src = ar_rsrc(p.comm[p.rank], (size_t) RANKS * p.slot_bytes);
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+        const ar_u32x4 v = *reinterpret_cast<const ar_u32x4*>(p.in + off);
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(v, dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
+    }
+    const bool ok = publish_and_wait<RANKS>(p, 0, w, &failed);
+    for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
+    {
+        ar_u32x4 vals[RANKS];
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i)
+            vals[i] = __builtin_amdgcn_raw_buffer_load_b128(src, (uint32_t) ((size_t) i * p.slot_bytes + off), 0, AR_SC_SYSTEM);
+#pragma unroll
+        for (int i = 0; i < RANKS; ++i) // all-ones bytes are a NaN in fp32, fp16 and bf16
+            *reinterpret_cast<ar_u32x4*>(p.out + (size_t) i * p.total_bytes + off)
+                = ok ? vals[i] : ar_u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    }
+}
+
 // invokeMultiGpuBarrier (customAllReduceKernels.cu:391-394): every rank has reached this point of its stream
 __global__ void multi_gpu_barrier_kernel(ArArgs p)
 {
@@ -396,6 +434,37 @@ void custom_all_reduce(mi355q_allreduce_params& params, void* data, size_t elts,
     case MI355Q_BF16: invoke<bf16_t>(params, strat, stream); break;
     default: MQ_CHECK(false, "Unsupported dataType for customAllReduce (%d)", dtype);
     }
+}
+
+// all-gather of `bytes_per_rank` bytes per rank into out[ranks * bytes_per_rank] (rank order)
+void custom_all_gather(mi355q_allreduce_params& q, const void* in, void* out, size_t bytes_per_rank, hipStream_t stream)
+{
+    check_params(q);
+    MQ_CHECK(in && out, "null tensor");
+    if (bytes_per_rank == 0)
+        return;
+    MQ_CHECK(bytes_per_rank % 16 == 0, "all-gather shard of %zu bytes: must be a multiple of 16", bytes_per_rank);
+    MQ_CHECK(((uintptr_t) in & 15) == 0 && ((uintptr_t) out & 15) == 0, "input / output must be 16-byte aligned");
+    const size_t ranks = q.ranks_per_node;
+    const size_t comm_bytes = q.comm_buffer_bytes ? q.comm_buffer_bytes : mi355q_allreduce_max_workspace_size((int) ranks);
+    q.local_output_buffer_ptr = out;
+    ArArgs a = to_args(q);
+    a.in = static_cast<const uint8_t*>(in);
+    a.total_bytes = bytes_per_rank;
+    a.slot_bytes = round_up(bytes_per_rank, 256);
+    MQ_CHECK(ranks * a.slot_bytes <= comm_bytes, "all-gather of %zu bytes x %zu ranks exceeds the %zu-byte comm buffer",
+        bytes_per_rank, ranks, comm_bytes);
+    const int blocks = (int) std::min<size_t>(AR_MAX_WGS, std::max<size_t>(1, div_up(bytes_per_rank, AR_MIN_CHUNK)));
+    a.chunk_bytes = round_up(div_up(bytes_per_rank, blocks), 16);
+    switch (ranks)
+    {
+    case 2: hipLaunchKernelGGL((all_gather_push_kernel<2>), dim3(blocks), dim3(AR_THREADS), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((all_gather_push_kernel<4>), dim3(blocks), dim3(AR_THREADS), 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((all_gather_push_kernel<6>), dim3(blocks), dim3(AR_THREADS), 0, stream, a); break;
+    case 8: hipLaunchKernelGGL((all_gather_push_kernel<8>), dim3(blocks), dim3(AR_THREADS), 0, stream, a); break;
+    default: MQ_CHECK(false, "customAllGather: ranks_per_node %zu (2, 4, 6, 8)", ranks);
+    }
+    MQ_HIP(hipGetLastError());
 }
 
 // invokeMultiGpuBarrier, :391-394

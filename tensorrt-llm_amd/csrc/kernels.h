@@ -87,6 +87,7 @@ void gated_silu(const mi355q_gated_act_params& p, hipStream_t stream);
 void allreduce_params_deserialize(
     mi355q_allreduce_params& out, const void* const* buffer_ptrs, size_t tpSize, size_t tpRank, uint32_t flag_value);
 void custom_all_reduce(mi355q_allreduce_params& params, void* data, size_t elts, int dtype, int strat, hipStream_t stream);
+void custom_all_gather(mi355q_allreduce_params& params, const void* in, void* out, size_t bytes_per_rank, hipStream_t stream);
 void multi_gpu_barrier_launch(const mi355q_allreduce_params& params, hipStream_t stream);
 void allreduce_alloc_timeout_flag(uint32_t** flag);
 void allreduce_free_timeout_flag(uint32_t* flag);

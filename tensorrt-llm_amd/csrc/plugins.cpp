@@ -754,6 +754,91 @@ struct AllReducePlugin : PluginBase
     }
 };
 
+// ===================================================================== AllGather
+// plugins/ncclPlugin/allgatherPlugin.{h,cpp}: input 0 the local tensor (type_id); output = the group's tensors back to
+// back along dim 0 (:66-72, :96-110).  The reference calls ncclAllGather on an MPI-bootstrapped communicator; here the
+// gather runs on the custom all-reduce's IPC buffers, so the plugin takes the same second input as AllReduce (the HOST
+// int64 workspace table); messages that do not fit go through the host side's RCCL call (mi355q/tp.py).
+struct AllGatherPlugin : PluginBase
+{
+    std::vector<int32_t> mGroup;
+    int32_t mType;
+    int32_t mCounter, mRank;
+    AllGatherPlugin(std::vector<int32_t> group, int type, int counter, int rank)
+        : mGroup(std::move(group))
+        , mType(type)
+        , mCounter(counter)
+        , mRank(rank)
+    {
+        MQ_CHECK(dtype_size(mType) > 0, "AllGather: data type %d", mType);
+    }
+    const char* type() const override
+    {
+        return "AllGather";
+    }
+    PluginBase* clone() const override
+    {
+        return new AllGatherPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int, mi355q_dims* out) const override // :66-72
+    {
+        MQ_CHECK(idx == 0, "outputIndex %d", idx);
+        *out = in[0];
+        out->d[0] *= (int) mGroup.size();
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int) const override // :74-79
+    {
+        if (pos == 1 && nbIn == 2)
+            return io[pos].type == MI355Q_INT64 && io[pos].format == 0;
+        return io[pos].type == mType && io[pos].format == 0;
+    }
+    int getOutputDataType(int idx, const int32_t* inTypes, int) const override
+    {
+        MQ_CHECK(idx == 0, "index %d", idx);
+        return inTypes[0];
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
+        void* const* outputs, void*, hipStream_t stream) override // :90-110
+    {
+        const int64_t size = dims_prod(inDesc[0].dims, 0, inDesc[0].dims.nbDims);
+        const int len = inDesc[1].dims.d[0];
+        const int nRanks = (int) mGroup.size();
+        MQ_CHECK(nRanks >= 2 && (len == 4 * nRanks || len == 4 * nRanks + 2), "all_reduce_workspace length %d for %d ranks",
+            len, nRanks);
+        const int64_t* table = static_cast<const int64_t*>(inputs[1]);
+        int myRank = mRank;
+        if (myRank < 0)
+        {
+            const char* e = getenv("RANK");
+            MQ_CHECK(e, "AllGather: no 'rank' field and no RANK in the environment");
+            myRank = atoi(e);
+        }
+        myRank %= nRanks;
+        mi355q_allreduce_params params;
+        allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, mCounter);
+        params.comm_buffer_bytes = mi355q_allreduce_max_workspace_size(nRanks);
+        if (len == 4 * nRanks + 2)
+        {
+            params.comm_buffer_bytes = (size_t) table[4 * nRanks];
+            params.timeout_flag = reinterpret_cast<uint32_t*>(table[4 * nRanks + 1]);
+            if (params.timeout_flag)
+                MQ_CHECK(*static_cast<volatile uint32_t*>(params.timeout_flag) == 0,
+                    "AllGather: an earlier collective timed out waiting for a peer rank");
+        }
+        custom_all_gather(params, inputs[0], outputs[0], (size_t) size * dtype_size(mType), stream);
+    }
+    size_t serializationSize() const override // :147-150: type, then the group
+    {
+        return sizeof(int32_t) + sizeof(int32_t) * mGroup.size();
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mType);
+        for (int32_t g : mGroup)
+            write(buf, g);
+    }
+};
+
 // ===================================================================== Fp8Gemm (no reference plugin)
 // inputs: 0 A e4m3 [.., K]; 1 B e4m3 [N, K]; 2 scale_a fp32 [1]; 3 scale_b fp32 [1]
 struct Fp8GemmPlugin : PluginBase
@@ -1275,7 +1360,7 @@ GptAttentionFields parse_attention_fields(const FieldReader& r) // gptAttentionP
 
 const char* const kPluginNames[] = {"WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
     "QuantizePerToken", "GPTAttention", "Fp8Gemm", "QuantizeTensor", "RmsnormQuantization", "LayernormQuantization",
-    "AllReduce", nullptr};
+    "AllReduce", "AllGather", nullptr};
 
 PluginBase* create_plugin(const char* name, const FieldReader& r)
 {
@@ -1299,6 +1384,14 @@ PluginBase* create_plugin(const char* name, const FieldReader& r)
         return new Fp8GemmPlugin(r.req_int("type_id"));
     if (n == "QuantizeTensor")
         return new QuantizeTensorPlugin();
+    if (n == "AllGather") // createPlugin, allgatherPlugin.cpp:190-230
+    {
+        const mi355q_plugin_field* g = r.find("group");
+        MQ_CHECK(g && g->type == MI355Q_FIELD_INT32 && g->length > 0, "AllGather: field 'group' (int32 list) is missing");
+        const int32_t* gi = static_cast<const int32_t*>(g->data);
+        return new AllGatherPlugin(std::vector<int32_t>(gi, gi + g->length), r.req_int("type_id"), r.opt_int("counter", 0),
+            r.opt_int("rank", -1));
+    }
     if (n == "AllReduce") // createPlugin, allreducePlugin.cpp:306-350
     {
         const mi355q_plugin_field* g = r.find("group");
@@ -1384,6 +1477,16 @@ PluginBase* deserialize_plugin(const char* name, const void* data, size_t length
     {
         need(0);
         out = new QuantizeTensorPlugin();
+    }
+    else if (n == "AllGather") // allgatherPlugin.cpp:36-54: type, then the group to the end
+    {
+        MQ_CHECK(length >= 4 && (length - 4) % 4 == 0, "Expected length (%d) != real length", (int) length);
+        int32_t t;
+        read(d, t);
+        std::vector<int32_t> group((length - 4) / 4);
+        for (auto& g : group)
+            read(d, g);
+        out = new AllGatherPlugin(group, t, 0, -1);
     }
     else if (n == "AllReduce") // allreducePlugin.cpp:42-62: type, strategy, counter, then the group to the end
     {
@@ -1841,6 +1944,17 @@ extern "C"
             {
                 MQ_CHECK(out, "null argument");
                 allreduce_params_deserialize(*out, buffer_ptrs, tpSize, tpRank, flag_value);
+            });
+    }
+
+    mi355q_status mi355q_custom_all_gather(
+        mi355q_allreduce_params* params, const void* input, void* output, size_t bytes_per_rank, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                custom_all_gather(*params, input, output, bytes_per_rank, static_cast<hipStream_t>(stream));
             });
     }
 

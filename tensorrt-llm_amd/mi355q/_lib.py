@@ -193,6 +193,7 @@ SYMBOLS = {
     "mi355q_allreduce_max_workspace_size": (_sz, [_i32]),
     "mi355q_allreduce_params_deserialize": (_i32, [C.POINTER(AllReduceParams), _PP, _sz, _sz, C.c_uint32]),
     "mi355q_custom_all_reduce": (_i32, [C.POINTER(AllReduceParams), _vp, _sz, _i32, _i32, _vp]),
+    "mi355q_custom_all_gather": (_i32, [C.POINTER(AllReduceParams), _vp, _vp, _sz, _vp]),
     "mi355q_multi_gpu_barrier": (_i32, [C.POINTER(AllReduceParams), _vp]),
     "mi355q_allreduce_barrier_bytes": (_sz, []),
     "mi355q_allreduce_alloc_timeout_flag": (_i32, [_PP]),

@@ -135,3 +135,29 @@ class CustomAllReduceHelper:
                                    ("rank", self.rank, L.FIELD_INT32)])
         plg.enqueue([tensor, self.workspace], [out])
         return out
+
+    def allgather(self, tensor, out=None, direct=False):
+        """functional.py `allgather(tensor, group)` (AllGather plugin, allgatherPlugin.cpp:90-110): the ranks' tensors
+        back to back along dim 0.  Messages that fit the comm buffer take the push kernel over the peer mappings;
+        larger ones (or sizes that are not a multiple of 16 bytes) go to RCCL."""
+        tensor = tensor.contiguous()
+        nbytes = tensor.numel() * tensor.element_size()
+        shape = (tensor.shape[0] * self.world, ) + tuple(tensor.shape[1:])
+        out = torch.empty(shape, dtype=tensor.dtype, device=tensor.device) if out is None else out
+        slot = (nbytes + 255) // 256 * 256
+        if nbytes % 16 or slot * self.world > self.size:
+            dist.all_gather(list(out.chunk(self.world, dim=0)), tensor, group=self.group)
+            return out
+        self.counter += 1
+        if direct:
+            if self.timed_out():
+                raise RuntimeError("custom all-gather: an earlier collective timed out waiting for a peer rank")
+            p = self._params(tensor, out)
+            L.check(L.lib().mi355q_custom_all_gather(C.byref(p), tensor.data_ptr(), out.data_ptr(), nbytes,
+                                                     current_stream_ptr()))
+            return out
+        plg = Plugin("AllGather", [("group", list(range(self.world)), L.FIELD_INT32),
+                                   ("type_id", torch_dtype_to_trt(tensor.dtype), L.FIELD_INT32),
+                                   ("counter", self.counter, L.FIELD_INT32), ("rank", self.rank, L.FIELD_INT32)])
+        plg.enqueue([tensor, self.workspace], [out])
+        return out

@@ -86,20 +86,26 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
-def all_gather_last_dim(t: torch.Tensor, group=None) -> torch.Tensor:
-    """allgather plugin + the transpose the reference does for gather_output (layers.py:516-518)."""
+def all_gather_last_dim(t: torch.Tensor, group=None, helper=None) -> torch.Tensor:
+    """allgather plugin + the transpose the reference does for gather_output (layers.py:516-518).  `helper`: a
+    mi355q.ipc.CustomAllReduceHelper, whose AllGather plugin (the push kernel over the peer mappings) then does the
+    gather along dim 0; without one the gather is torch.distributed's (RCCL on the GPU box, gloo on the CPU)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t
-    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    world = dist.get_world_size(group)
+    if helper is not None:
+        g = helper.allgather(t.contiguous().unsqueeze(0))           # [world, ..., N_local]
+        return torch.cat(list(g.unbind(0)), dim=-1)
+    parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t.contiguous(), group=group)
     return torch.cat(parts, dim=-1)
 
 
-def column_parallel_linear(x, shard: WoqShard, matmul: Callable, gather_output=False, group=None):
+def column_parallel_linear(x, shard: WoqShard, matmul: Callable, gather_output=False, group=None, helper=None):
     """y_local[M, N_local] = matmul(x, shard) (+ local bias); no collective unless gather_output."""
     assert shard.parallel == "column"
     y = matmul(x, shard, shard.bias)
-    return all_gather_last_dim(y, group) if gather_output else y
+    return all_gather_last_dim(y, group, helper) if gather_output else y
 
 
 def row_parallel_linear(x_local, shard: WoqShard, matmul: Callable, group=None):

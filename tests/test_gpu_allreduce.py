@@ -2,7 +2,7 @@
 it, with the ranks as separate PROCESSES that map each other's buffers through HIP IPC.  The box has one GPU, so all
 ranks sit on device 0: this exercises the kernels' indexing, per-workgroup flag protocol, ping-pong buffers, the
 T-arithmetic summation order bit for bit against the oracle, and the bounded wait (a late rank -> NaN output + the
-host-visible timeout word), but NOT the cross-GPU (xGMI) visibility of the flags -- DESIGN.md says so."""
+host-visible timeout word), but NOT the cross-GPU (xGMI) visibility of the flags -- DESIGN.md says so.  The AllGather plugin (allgatherPlugin.cpp) runs on the same buffers in the same workers."""
 import os
 import sys
 
@@ -56,6 +56,31 @@ def _worker(rank, world, port, results):
             torch.cuda.synchronize()
             if not torch.equal(y.cpu(), torch.full((256,), world * (world + 1) / 2, dtype=torch.float16)):
                 ok, msg = False, f"rank {rank} AUTO small: {y[:4].tolist()}"
+        if ok:
+            # AllGather (allgatherPlugin.cpp:90-110) on the same buffers, interleaved with all-reduces so the ping-pong
+            # counter and flags are shared: out = the ranks' tensors back to back along dim 0, byte for byte
+            gcases = [(torch.float16, (1, 8)), (torch.bfloat16, (3, 1000)), (torch.float32, (64, 1024)),
+                      (torch.int8, (16, 4096)), (torch.float16, (512, 1024)), (torch.float16, (5, 3))]  # last: RCCL/gloo
+            for ci, (dtype, shape) in enumerate(gcases):
+                g = torch.Generator().manual_seed(77 + ci)
+                n = shape[0] * shape[1]
+                parts = [(torch.randn(n, generator=g) * 50).to(dtype).reshape(shape) for _ in range(world)]
+                if dtype == torch.float16 and shape == (5, 3):
+                    x = parts[rank].clone()                 # 30 bytes: not a multiple of 16 -> torch.distributed (gloo: CPU)
+                    y = helper.allgather(x)
+                else:
+                    y = helper.allgather(parts[rank].to(dev), direct=bool(ci & 1))
+                    torch.cuda.synchronize()
+                    helper.allreduce(torch.ones(64, dtype=torch.float16, device=dev), strategy=L.AR_ONESHOT)
+                ref = torch.cat(parts, dim=0)
+                if y.shape != ref.shape or not torch.equal(y.cpu().view(torch.uint8), ref.view(torch.uint8)):
+                    ok, msg = False, f"rank {rank} allgather {dtype} {shape}: {y.flatten()[:4].tolist()} vs {ref.flatten()[:4].tolist()}"
+                    break
+            if ok:  # a shard that does not fit ranks * slot in the comm buffer goes to torch.distributed too
+                big = torch.zeros((8 << 20) // world + 256, dtype=torch.uint8)
+                y = helper.allgather(big)
+                ok = y.shape[0] == big.shape[0] * world
+                msg = "" if ok else f"rank {rank} allgather fallback shape {tuple(y.shape)}"
         dist.barrier()
         helper.close()
         if ok and world == 2:

@@ -32,7 +32,7 @@ def test_version_and_plugin_names():
     assert b"gfx950" in L.lib().mi355q_version()
     assert get_plugin_names() == ["WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
                                   "QuantizePerToken", "GPTAttention", "Fp8Gemm", "QuantizeTensor",
-                                  "RmsnormQuantization", "LayernormQuantization", "AllReduce"]
+                                  "RmsnormQuantization", "LayernormQuantization", "AllReduce", "AllGather"]
 
 
 @pytest.mark.parametrize("qt,tq", [(oracle.INT8_W, torch.int8), (oracle.INT4_W, torch.quint4x2)])
@@ -249,6 +249,13 @@ def test_allreduce_plugin_fields_serialization_and_deserialize_params():
     assert Plugin.deserialize("AllReduce", blob).serialize() == blob
     assert plg.get_output_dimensions(0, [[5, 8192], [16]]) == [5, 8192]
     # RING is the host's RCCL call: the plugin says so instead of running something else
+    # AllGather (allgatherPlugin.cpp:36-54, :66-72, :147-160): type then the group; dim 0 times the group size
+    ag = Plugin("AllGather", [("group", [0, 1, 2, 3], L.FIELD_INT32), ("type_id", L.HALF, L.FIELD_INT32)])
+    assert ag.get_output_dimensions(0, [[6, 5, 7], [18]]) == [24, 5, 7]
+    agblob = ag.serialize()
+    assert len(agblob) == 4 + 4 * 4 and Plugin.deserialize("AllGather", agblob).serialize() == agblob
+    with pytest.raises(Exception):
+        Plugin("AllGather", [("type_id", L.HALF, L.FIELD_INT32)])
     ring = Plugin("AllReduce", [("group", [0, 1], L.FIELD_INT32), ("type_id", L.HALF, L.FIELD_INT32),
                                 ("strategy", L.AR_RING, L.FIELD_INT8), ("counter", 0, L.FIELD_INT32)])
     with pytest.raises(L.Mi355qError, match="RING"):
