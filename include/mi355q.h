@@ -337,6 +337,9 @@ extern "C"
         const void* kv_linear_buffer; /* NULL, or the contiguous cache of KVLinearBuffer (kvCacheUtils.h:241-338):
                                        [batch, 2, Hkv, linear_max_seq_len, Dh] in kv_type; block_pointers is then unused */
         int32_t linear_max_seq_len;
+        /* ALiBi (position_embedding_type 3 / 4; decoderMaskedMultiheadAttentionTemplate.h:1891-1895, :2026): act_type
+         * [num_heads] slopes, score += slope[h] * (t - tlength); NULL otherwise */
+        const void* alibi_slopes;
     } mi355q_decode_attention_params;
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
     mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);
@@ -384,6 +387,20 @@ extern "C"
         const void* kv_linear_buffer; /* NULL, or the contiguous cache of KVLinearBuffer (kvCacheUtils.h:241-338):
                                        [batch, 2, Hkv, linear_max_seq_len, Dh] in kv_type; block_pointers is then unused */
         int32_t linear_max_seq_len;
+        /* chunked context (use_paged_context_fmha, gptAttentionCommon.cpp:825-864; kv_seq_lengths of
+         * unfusedAttentionKernels_2_template.h:252-256): device [batch] tokens of each sequence INCLUDING this call's, or
+         * NULL (= context_lengths: nothing cached yet).  The call's tokens take positions sequence_lengths -
+         * context_lengths .. and attend to every earlier token through the cache (16-bit caches only, as the reference). */
+        const int32_t* sequence_lengths;
+        int32_t max_kv_length;      /* host bound of sequence_lengths (max_past_kv_len); 0 = max_context_length */
+        /* sliding window attention (gptKernels.cu:174-177: key t visible to query a iff a - window <= t <= a) and the
+         * cyclic cache the append follows (kvCacheUtils.h:71-117; the sink tokens and the last window - sink tokens are
+         * kept, unfusedAttentionKernels_2_template.h:336-340).  0 = no window. */
+        int32_t cyclic_attention_window_size;
+        int32_t sink_token_length;
+        /* ALiBi (position_embedding_type 3 / 4): T [num_heads] slopes, score += slope[h] * (t - a)
+         * (unfusedAttentionKernels.cu:212-218); NULL otherwise */
+        const void* alibi_slopes;
     } mi355q_context_attention_params;
     size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params);
     mi355q_status mi355q_context_attention(const mi355q_context_attention_params* params, void* stream);

@@ -408,13 +408,14 @@ def quantize_kv(x, kv_dtype, scale_orig_quant):
 
 def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_scaling=1.0, rope=None,
                      rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None, kv_scale_orig_quant=1.0,
-                     kv_scale_quant_orig=1.0, update_cache=True):
+                     kv_scale_quant_orig=1.0, update_cache=True, alibi_slopes=None):
     """One generation step of GPTAttention over a paged cache, restating the MMHA math
     (decoderMaskedMultiheadAttentionTemplate.h; conventions pinned by test_gpt_attention.py:1018,1154):
       * seq_lens[b] INCLUDES the current token; tlength = seq_lens[b]-1 cached tokens (:1480-1482)
       * q = qkv[:, :Hq*Dh], k = next Hkv*Dh, v = last Hkv*Dh (gptAttentionCommon.cpp:271-306)
       * bias add, then RoPE at position tlength, results rounded to T (:1602-1711)
-      * logits = (q.k) * 1/(sqrt(Dh)*q_scaling) in fp32 (:1797, :2026)
+      * logits = (q.k) * 1/(sqrt(Dh)*q_scaling) in fp32 (:1797, :2026); ALiBi (alibi_slopes [Hq] in T, :1891-1895):
+        + slope[h] * (t - tlength) (:2026)
       * p = exp(l - max); out = sum p v / (sum p + 1e-6)  (:2259-2290)
       * the current token uses its un-quantised k/v (registers), cached tokens are dequantised as
         float(k8) * kv_scale_quant_orig (:1999-2003); new k/v are appended at position tlength.
@@ -450,6 +451,8 @@ def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_
             for g in range(grp):
                 h = hk * grp + g
                 logits = (kk @ torch.from_numpy(q[h]).double()).float() * np.float32(inv_sqrt)
+                if alibi_slopes is not None:
+                    logits = logits + alibi_slopes[h].float() * (torch.arange(tl + 1) - tl).float()
                 p = torch.exp(logits - logits.max())
                 o = (p.double() @ vv).float() / (p.sum() + 1e-6)
                 out[b, h * D:(h + 1) * D] = o
@@ -583,7 +586,7 @@ def apply_rope_rows(x, positions, rot_dim, kind, base=10000.0, scale=1.0):
 
 def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_dim, cache=None, q_scaling=1.0,
                       rope=None, rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None,
-                      kv_scale_orig_quant=1.0):
+                      kv_scale_orig_quant=1.0, past_lens=None, window=None, cmap=None, alibi_slopes=None):
     """The context phase of GPTAttention (gptAttentionCommon.cpp:641-1133 enqueueContext), restated:
       * per input token: bias add in T, RoPE at the token's position in its sequence, rounded to T
         (invokeApplyBiasRopeUpdateKVCache / invokeAddFusedQKVBiasTranspose, unfusedAttentionKernels.cu);
@@ -593,8 +596,16 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
         unfused path (:1000-1120: cuBLAS QK^T, invokeMaskedSoftmax, cuBLAS PV); the un-quantised K / V are
         used, as in the reference's context FMHA.  Scale 1/(sqrt(Dh) q_scaling), normaliser sum + 1e-6
         like the MMHA kernel (the 1e-6 is below T's resolution).
+      * past_lens (chunked context, use_paged_context_fmha, :825-864): the sequence already holds past tokens in the
+        cache; the input tokens take positions past .. (RoPE and cache position, unfusedAttentionKernels_2_template.h:
+        252-262) and attend to every earlier token through the (16-bit) cache;
+      * window (cyclic_attention_window_size): key t is visible to the query at position a iff a - window <= t <= a
+        (gptKernels.cu:174-177); cmap (CyclicMap): the append keeps the sink tokens and the last window - sink tokens, at
+        their cyclic slots (unfusedAttentionKernels_2_template.h:336-340);
+      * alibi_slopes [Hq] in T: score += slope[h] * (t - a) (unfusedAttentionKernels.cu:212-218).
     qkv_rows: list of torch [len_b, (Hq+2Hkv)*Dh] in T, one per sequence.  Returns a list of [len_b, Hq*Dh] in T.
-    Tolerance parity like decode_attention (the reference rounds P to T before P.V)."""
+    Tolerance parity like decode_attention (the reference rounds P to T before P.V).  No test of the reference covers
+    chunked context, the sliding window or ALiBi in the context phase: those three are "parity unpinned"."""
     Hq, Hkv, D = num_heads, num_kv_heads, head_dim
     inv_sqrt = np.float32(1.0 / (math.sqrt(D) * q_scaling))
     grp = Hq // Hkv
@@ -607,8 +618,10 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
         if qkv_bias is not None:
             x = x + qkv_bias.reshape(1, -1).to(T)
         x = x.float().numpy().reshape(S, Hq + 2 * Hkv, D).copy()
+        past = 0 if past_lens is None else int(past_lens[b])
+        kv_len = past + S
+        pos = past + np.arange(S)
         if rope is not None:
-            pos = np.arange(S)
             x[:, :Hq + Hkv] = apply_rope_rows(x[:, :Hq + Hkv], pos, rot_dim, rope, rope_base, rope_scale)
             x = torch.from_numpy(x).to(T).float().numpy()
         q = torch.from_numpy(x[:, :Hq]).double()                 # [S, Hq, D]
@@ -617,13 +630,28 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
         if cache is not None:
             for hk in range(Hkv):
                 for t in range(S):
-                    cache.write(b, 0, hk, t, quantize_kv(k[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
-                    cache.write(b, 1, hk, t, quantize_kv(v[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
+                    a, slot = int(pos[t]), int(pos[t])
+                    if cmap is not None:
+                        if not (a < cmap.sink or a >= max(kv_len - cmap.window + cmap.sink, cmap.sink)):
+                            continue
+                        slot = cmap.slot(a)
+                    cache.write(b, 0, hk, slot, quantize_kv(k[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
+                    cache.write(b, 1, hk, slot, quantize_kv(v[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
+        if past > 0:  # every key of the sequence, as the cache holds it
+            assert cache is not None and cache.dtype == T
+            k = torch.stack([cache.gather(b, 0, hk, kv_len) for hk in range(Hkv)], 1).double()
+            v = torch.stack([cache.gather(b, 1, hk, kv_len) for hk in range(Hkv)], 1).double()
         out = torch.zeros(S, Hq, D, dtype=torch.float32)
-        mask = torch.tril(torch.ones(S, S, dtype=torch.bool))
+        tq = torch.from_numpy(pos)[:, None]
+        tk = torch.arange(kv_len)[None, :]
+        mask = tk <= tq
+        if window is not None:
+            mask &= tk >= tq - window
         for h in range(Hq):
             hk = h // grp
             logits = (q[:, h] @ k[:, hk].t()).float() * inv_sqrt
+            if alibi_slopes is not None:
+                logits = logits + alibi_slopes[h].float() * (tk - tq).float()
             logits = logits.masked_fill(~mask, float("-inf"))
             p = torch.exp(logits - logits.max(dim=1, keepdim=True).values)
             out[:, h] = (p.double() @ v[:, hk]).float() / (p.sum(dim=1, keepdim=True) + 1e-6)

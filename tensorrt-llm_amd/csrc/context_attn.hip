@@ -13,8 +13,13 @@
 //        S^T = K . Q^T (K fragments by ds_read_b128, Q^T fragments resident in registers), online softmax per
 //        query column in the log2 domain, the probability registers ARE the B fragment of O^T += V^T . P^T,
 //        V^T fragments by the transposing LDS read (ds_read_b64_tr_b16) from the row-major V tile.
-// Scope: causal mask, fp16 / bf16, head size 64 / 128, MHA / GQA / MQA, padded or packed input, paged cache;
-// the attention uses the un-quantised K / V of the input tokens (as the reference's context FMHA does).
+// Scope: causal mask (optionally the sliding window, gptKernels.cu:174-177), ALiBi slopes, fp16 / bf16, head size
+// 64 / 128, MHA / GQA / MQA, padded or packed input, paged or linear cache; the attention uses the un-quantised K / V
+// of the input tokens (as the reference's context FMHA does).
+// Chunked context (use_paged_context_fmha, gptAttentionCommon.cpp:825-864): when a sequence already has `past` tokens
+// in its cache, the input tokens take positions past .. past + len - 1, are appended there, and the attention kernel
+// (CACHED form) streams K / V of ALL kv_len = past + len tokens out of the cache itself (16-bit caches only, as in the
+// reference: "Paged Context FMHA doesn't work with fp8/int8 kv cache").
 #include "decode_common.h"
 
 namespace mi355q
@@ -50,17 +55,21 @@ __device__ __forceinline__ float ctx_max3(float a, float b, float c)
 
 // max over lane ^ 16 (W = 16) or lane ^ 32 (W = 32) through v_permlane{16,32}_swap: with both operands holding x
 // the two results are [x0 x0 x2 x2] / [x1 x1 x3 x3] by rows of 16 lanes (W = 16) or [lo lo] / [hi hi] by halves
-// (W = 32), so their max is the pairwise all-reduce.  The second operand goes through an empty asm: hipcc folds the
-// two results of the builtin into one when it can prove the operands equal.
+// (W = 32), so their max is the pairwise all-reduce.  The swap and the max sit in ONE asm statement: given the builtin,
+// hipcc treats the swap's two results as the same value when its operands are copies of each other and emits
+// max(r0, r0) -- every lane then ends up with the first row's maximum instead of the column's (found in round 2: a
+// consistent but too small running maximum, harmless until a sliding window leaves that row with nothing but masked
+// scores).  s_nop 1 either side: a VALU write needs 2 wait states before the swap reads it, and the swap's results
+// 2 before a VALU reads them; the compiler cannot see inside the statement to add them.
 template <int W>
 __device__ __forceinline__ float ctx_swap_max(float x)
 {
-    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
-    asm("" : "+v"(b));
-    const auto r = W == 16 ? __builtin_amdgcn_permlane16_swap(a, b, false, false) : __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    float m;
-    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(__builtin_bit_cast(float, r[0])), "v"(__builtin_bit_cast(float, r[1])));
-    return m;
+    float a = x, b = x;
+    if constexpr (W == 16)
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    else
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    return a;
 }
 
 struct CtxArgs
@@ -81,7 +90,28 @@ struct CtxArgs
     size_t linear_plane_bytes;
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale, score_scale;
+    const int32_t* kv_lens;   // device [B]: tokens of the sequence INCLUDING this call's (past + len), or null (no past)
+    int mask_window;          // sliding window: key t is visible to the query at position a iff a - mask_window <= t <= a
+    int kv_window, sink, bubble, cyc_len; // cache slot map of the append (kvCacheUtils.h:71-117); identity without a window
+    const uint16_t* alibi_slopes;         // T [Hq] or null: score += slope[h] * (t - a)
 };
+
+__device__ __forceinline__ int ctx_kv_slot(const CtxArgs& p, int t)
+{
+    return t < p.sink ? t : p.sink + p.bubble + (t - p.sink) % p.cyc_len;
+}
+// tokens already in the cache before this call's (chunked context: kv_seq_lengths - q_seq_lengths,
+// unfusedAttentionKernels_2_template.h:252-256)
+__device__ __forceinline__ int ctx_past(const CtxArgs& p, int b, int len)
+{
+    return p.kv_lens ? max(p.kv_lens[b] - len, 0) : 0;
+}
+// the append keeps the sink tokens and the last (window - sink) tokens of the sequence (:336-339; with a past the
+// bound is taken on the whole kv length, where the reference takes the chunk's and lets two tokens race for a slot)
+__device__ __forceinline__ bool ctx_keeps(const CtxArgs& p, int pos, int kv_len)
+{
+    return pos < p.sink || pos >= max(kv_len - p.kv_window + p.sink, p.sink);
+}
 
 // base of the K (kv = 0) or V (kv = 1) block `blk` of sequence b (getKBlockPtr / getVBlockPtr)
 __device__ __forceinline__ char* ctx_block_ptr(const CtxArgs& p, int b, int kv, int blk)
@@ -129,8 +159,10 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
             x = T16<T>::to_float(T16<T>::from_float(x + T16<T>::to_float(p.qkv_bias[i]))); // add in T
         xs[i] = x;
     }
-    const bool rope = p.pos_type == 1 || p.pos_type == 2; // kROPE_GPTJ / kROPE_GPT_NEOX on q and k heads, position s
+    const bool rope = p.pos_type == 1 || p.pos_type == 2; // kROPE_GPTJ / kROPE_GPT_NEOX on q and k heads, position pos
     const int half = p.rot_dim >> 1;
+    const int past = ctx_past(p, b, len);
+    const int pos = past + s;
     if (rope && (int) threadIdx.x < half) // the angles only depend on (position, pair index): one table per token
     {
         const int j = threadIdx.x;
@@ -146,7 +178,7 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         }
         else if (p.rot_scale_type == 1)
             scale = 1.f / scale;
-        const float ang = ((float) s * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
+        const float ang = ((float) pos * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
         float sn, cs;
         sincosf(ang, &sn, &cs);
         cs_tab[2 * j] = cs;
@@ -174,11 +206,12 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         const int e = 2 * i, vec = e / D, d = e % D;
         *reinterpret_cast<uint32_t*>(p.proc + ((size_t) vec * p.rows + row) * D + d) = pack2<T>(xs[e], xs[e + 1]);
     }
-    // cache append at position s: block [Hkv][tokens_per_block][Dh]
-    if (ctx_has_cache(p))
+    // cache append at the slot of position pos: block [Hkv][tokens_per_block][Dh]
+    if (ctx_has_cache(p) && ctx_keeps(p, pos, past + len))
     {
         const int tpb = 1 << p.tpb_log2;
-        const int blk = s >> p.tpb_log2, tin = s & (tpb - 1);
+        const int slot = ctx_kv_slot(p, pos);
+        const int blk = slot >> p.tpb_log2, tin = slot & (tpb - 1);
         const float qs = p.kv_type ? p.kv_scale_orig_quant[0] : 1.f;
         for (int i = threadIdx.x; i < 2 * Hkv * D / 4; i += 256) // 4 consecutive d per thread
         {
@@ -218,6 +251,8 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
     __shared__ float cs_tab[128]; // [j] cos | [64 + j] sin, j < rot_dim / 2 <= 64
     const bool rope = p.pos_type == 1 || p.pos_type == 2;
     const int half = p.rot_dim >> 1;
+    const int past = ctx_past(p, b, len);
+    const int pos = past + s;
     if (rope)
     {
         if ((int) threadIdx.x < half)
@@ -235,7 +270,7 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
             }
             else if (p.rot_scale_type == 1)
                 scale = 1.f / scale;
-            const float ang = ((float) s * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
+            const float ang = ((float) pos * scale) / powf(base, (float) (2 * j) / (float) p.rot_dim);
             float sn, cs;
             sincosf(ang, &sn, &cs);
             cs_tab[j] = cs;
@@ -245,8 +280,9 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
     }
     const int cpv = D / 16; // chunk pairs per vector: 8 / 4
     const int tpb = 1 << p.tpb_log2;
-    const int blk = s >> p.tpb_log2, tin = s & (tpb - 1);
-    const bool bp = ctx_has_cache(p);
+    const int slot = ctx_kv_slot(p, pos);
+    const int blk = slot >> p.tpb_log2, tin = slot & (tpb - 1);
+    const bool bp = ctx_has_cache(p) && ctx_keeps(p, pos, past + len);
     const float qs = (bp && p.kv_type) ? p.kv_scale_orig_quant[0] : 1.f;
     for (int it = threadIdx.x; it < nvec * cpv; it += 256)
     {
@@ -369,7 +405,9 @@ constexpr int CTX_QW = 32;   // query rows per wave
 
 // grid (Hq, ceil(max_len / (32 NWV)), B), block 64 NWV.  blockIdx.y counts query tiles from the END of the sequence so the
 // long (many key tiles) workgroups are dispatched first.
-template <typename T, int DH, int NWV>
+// CACHED: K / V of keys 0 .. kv_len - 1 come from the (16-bit) cache, the query rows sit at positions past .. (chunked
+// context); else from the workspace rows of this call (past = 0).  BIAS: ALiBi, scores biased before the softmax.
+template <typename T, int DH, int NWV, bool CACHED, bool BIAS>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void ctx_attn_kernel(CtxArgs p)
 {
     constexpr int CTX_QB = CTX_QW * NWV;    // query rows per workgroup: 128 (4 waves, short sequences) / 256 (8 waves)
@@ -401,6 +439,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         return;
     const int q0 = Q0 + wave * CTX_QW; // this wave's first query row
     const bool wave_live = q0 < len;
+    const int kv_len = CACHED ? max(p.kv_lens[b], len) : len; // keys of the sequence
+    const int past = kv_len - len;                            // position of query row 0
+    const int window = p.mask_window;
     const size_t row0 = (size_t) (p.offsets ? p.offsets[b] : b * p.max_len);
     const uint16_t* qbase = p.proc + ((size_t) h * p.rows + row0) * DH;
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.proc + ((size_t) (p.num_heads + hk) * p.rows + row0) * DH);
@@ -423,10 +464,51 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         krel[i] = row * ROWB + 16 * (dch ^ ksw(row));
         vrel[i] = row * ROWB + 16 * (dch ^ vsw(row));
     }
+    // CACHED: the lane's K / V block bases of the tile staged NEXT, loaded one tile ahead so that their latency hides
+    // behind a tile of compute (the values are only touched after the loop's own vmcnt(0))
+    uint64_t kblk[CACHED ? DPW : 1], vblk[CACHED ? DPW : 1];
+    auto fetch_blocks = [&](int tile)
+    {
+        if constexpr (CACHED)
+        {
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+            {
+                const int row = (wave * DPW + i) * RPD + drow;
+                const int t = min(tile * CTX_KT + row, kv_len - 1);
+                const int blk = t >> p.tpb_log2;
+                if (p.linear_base)
+                {
+                    kblk[i] = (uint64_t) (p.linear_base + ((size_t) b * 2) * p.linear_plane_bytes);
+                    vblk[i] = kblk[i] + p.linear_plane_bytes;
+                }
+                else
+                {
+                    kblk[i] = (uint64_t) p.block_ptrs[((size_t) b * 2) * p.max_blocks + blk];
+                    vblk[i] = (uint64_t) p.block_ptrs[((size_t) b * 2 + 1) * p.max_blocks + blk];
+                }
+            }
+        }
+    };
     auto stage = [&](int tile, int buf)
     {
         const int t0 = tile * CTX_KT;
-        if (t0 + CTX_KT <= len) // wave-uniform: the whole tile is inside the sequence
+        if constexpr (CACHED)
+        {
+            const int tmask = (1 << p.tpb_log2) - 1;
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+            {
+                const int d = wave * DPW + i;
+                const int row = d * RPD + drow;
+                const int t = min(t0 + row, kv_len - 1); // rows past the sequence re-read its last row (masked)
+                const size_t in_blk = ((size_t) hk * p.head_tokens + (t & tmask)) * ROWB;
+                const uint32_t kdst = lds_base + buf * STAGE_BYTES + d * 1024;
+                ctx_dma16(reinterpret_cast<const uint8_t*>(kblk[i]) + in_blk + 16 * (dch ^ ksw(row)), kdst);
+                ctx_dma16(reinterpret_cast<const uint8_t*>(vblk[i]) + in_blk + 16 * (dch ^ vsw(row)), kdst + TILE_BYTES);
+            }
+        }
+        else if (t0 + CTX_KT <= len) // wave-uniform: the whole tile is inside the sequence
         {
             const uint8_t* kt = kbase + (size_t) t0 * ROWB;
             const uint8_t* vt = vbase + (size_t) t0 * ROWB;
@@ -453,8 +535,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         }
     };
 
-    const int kv_end = min(len, Q0 + CTX_QB); // causal: keys 0 .. last query row of the workgroup
+    const int kv_end = min(kv_len, past + Q0 + CTX_QB); // causal: keys up to the last query row of the workgroup
     const int ntiles = (kv_end + CTX_KT - 1) / CTX_KT;
+    const int tile_lo = max(past + Q0 - window, 0) / CTX_KT; // sliding window: first key the workgroup's first row sees
 
     // Q^T fragments (B operand): column = query row q0 + 16*qt + lr, k = d = 32*ks + 8*lq + j
     uint4 qf[2][KS];
@@ -473,8 +556,15 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             asm volatile("" : "+v"(qf[qt][ks].x), "+v"(qf[qt][ks].y), "+v"(qf[qt][ks].z), "+v"(qf[qt][ks].w));
-    stage(0, 0);
-    const float sscale = p.score_scale * 1.4426950408889634f;
+    fetch_blocks(tile_lo);
+    stage(tile_lo, tile_lo & 1);
+    fetch_blocks(min(tile_lo + 1, ntiles - 1));
+    const float sscale_in = p.score_scale * 1.4426950408889634f;
+    // BIAS: the scores are scaled and biased in place (log2 domain), the softmax then runs with scale 1
+    const float sscale = BIAS ? 1.f : sscale_in;
+    float slope2 = 0.f;
+    if constexpr (BIAS)
+        slope2 = T16<T>::to_float(p.alibi_slopes[h]) * 1.4426950408889634f;
 
     float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
     cf32x4_t o[2][DT];
@@ -511,21 +601,32 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         // ---- mask (only tiles that cross the diagonal or the end of the sequence) + online softmax per query column.
         // The running maximum is kept on the RAW scores (sscale > 0) and the scale rides in the exponent's fma:
         // p = exp2(s * sscale - m * sscale)
-        const bool need_mask = t0 + CTX_KT - 1 > q0 || t0 + CTX_KT > len; // wave-uniform
+        const bool need_mask = t0 + CTX_KT - 1 > past + q0 || t0 + CTX_KT > kv_len
+            || t0 < past + q0 + CTX_QW - 1 - window; // wave-uniform: diagonal, end of the sequence, start of a row's window
         uint4 pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
         {
-            const int qpos = q0 + 16 * qt + lr;
+            const int qpos = past + q0 + 16 * qt + lr;
+            if constexpr (BIAS)
+            {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        s[x][qt][rr] = __builtin_fmaf(s[x][qt][rr], sscale_in, slope2 * (float) (t0 + 16 * x + 4 * lq + rr - qpos));
+            }
             if (need_mask)
             {
+                // -inf, not NEG_BIG: a row whose keys of this tile are all masked (sliding window) keeps m_run = NEG_BIG,
+                // and exp2(-inf - m_run) is still 0
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
                     {
                         const int t = t0 + 16 * x + 4 * lq + rr;
-                        s[x][qt][rr] = (t <= qpos && t < len) ? s[x][qt][rr] : NEG_BIG;
+                        s[x][qt][rr] = (t <= qpos && t < kv_len && t >= qpos - window) ? s[x][qt][rr] : -__builtin_inff();
                     }
             }
             float mx = ctx_max3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
@@ -549,8 +650,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
                     for (int rr = 0; rr < 4; ++rr)
                         o[qt][dt][rr] *= corr;
             }
-            // key 0 is visible to every query row, so m_run is a real score from the first tile on and a masked
-            // score gives exp2(-huge) = 0
+            // a masked score is -inf: exp2(-inf + anything finite) = 0, also while m_run is still NEG_BIG
             const float msc = -m_run[qt] * sscale;
             float pr[4][4];
             float ls = 0.f;
@@ -591,14 +691,18 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         }
     };
 
-    for (int i = 0; i < ntiles; ++i)
+    for (int i = tile_lo; i < ntiles; ++i)
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of tile i has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of tile i has landed (and the next tile's block bases)
         __syncthreads();                                  // everyone's has, and everyone is done with tile i-1
         if (i + 1 < ntiles)
+        {
             stage(i + 1, (i + 1) & 1);
+            fetch_blocks(min(i + 2, ntiles - 1));
+        }
         const int t0 = i * CTX_KT;
-        if (wave_live && t0 < q0 + CTX_QW) // wave-uniform: tiles past this wave's last row are fully masked
+        // wave-uniform: tiles past this wave's last row, or before its first row's window, are fully masked
+        if (wave_live && t0 < past + q0 + CTX_QW && t0 + CTX_KT > past + q0 - window)
             compute(i & 1, t0);
     }
 
@@ -666,10 +770,45 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     a.head_size = q.head_size;
     a.max_blocks = q.max_blocks_per_seq;
     a.kv_type = q.kv_type == q.act_type ? 0 : (q.kv_type == MI355Q_INT8 ? 1 : 2);
+    // chunked context: the sequences already hold sequence_lengths - context_lengths tokens in the cache
+    const bool cached = q.sequence_lengths != nullptr;
+    const int max_kv = cached ? std::max(q.max_kv_length, q.max_context_length) : q.max_context_length;
+    const bool has_cache = q.kv_linear_buffer || q.block_pointers;
+    const int capacity = q.kv_linear_buffer ? q.linear_max_seq_len : q.max_blocks_per_seq * q.tokens_per_block;
+    // sliding window (cyclic_attention_window_size): mask rule of gptKernels.cu:174-177, and the cache keeps the sink
+    // tokens + the last window - sink tokens at their cyclic slots (unfusedAttentionKernels_2_template.h:336-340)
+    const bool windowed = q.cyclic_attention_window_size > 0;
+    a.mask_window = windowed ? q.cyclic_attention_window_size : (1 << 29);
+    a.kv_window = 1 << 29;
+    a.sink = a.bubble = 0;
+    a.cyc_len = 1 << 29;
+    MQ_CHECK(q.sink_token_length >= 0, "sink_token_length %d", q.sink_token_length);
+    if (has_cache && (windowed || q.sink_token_length > 0))
+    {
+        const CyclicLayout cl = cyclic_layout(q.kv_linear_buffer != nullptr, capacity, q.max_blocks_per_seq, q.tokens_per_block,
+            q.cyclic_attention_window_size, q.sink_token_length);
+        a.kv_window = cl.window;
+        a.sink = cl.sink;
+        a.bubble = cl.bubble;
+        a.cyc_len = cl.cyc_len;
+    }
+    if (cached)
+    {
+        MQ_CHECK(has_cache, "sequence_lengths (chunked context) needs a cache to read the earlier tokens from");
+        MQ_CHECK(a.kv_type == 0, "chunked context reads K / V from the cache: 16-bit caches only (the reference: \"Paged Context "
+                                 "FMHA doesn't work with fp8/int8 kv cache\")");
+        // the kernel indexes the cache by position: every token of the sequence must still sit at its own slot
+        MQ_CHECK(q.sink_token_length == 0 && max_kv <= a.kv_window,
+            "chunked context over a wrapped cyclic cache is not built (kv length %d, window %d, sink %d)", max_kv, a.kv_window,
+            q.sink_token_length);
+        a.kv_lens = q.sequence_lengths;
+    }
+    if (q.alibi_slopes)
+        a.alibi_slopes = reinterpret_cast<const uint16_t*>(q.alibi_slopes);
     if (q.kv_linear_buffer)
     {
-        MQ_CHECK(q.linear_max_seq_len >= q.max_context_length, "max_context_length %d exceeds the linear cache (%d tokens per sequence)",
-            q.max_context_length, q.linear_max_seq_len);
+        MQ_CHECK(windowed || q.linear_max_seq_len >= max_kv, "kv length %d exceeds the linear cache (%d tokens per sequence)",
+            max_kv, q.linear_max_seq_len);
         MQ_CHECK(q.kv_type == q.act_type || q.kv_type == MI355Q_INT8 || q.kv_type == MI355Q_FP8, "kv cache type %d", q.kv_type);
         if (a.kv_type)
             MQ_CHECK(q.kv_scale_orig_quant, "8-bit kv cache needs kv_scale_orig_quant");
@@ -685,9 +824,8 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
         a.head_tokens = q.tokens_per_block;
         MQ_CHECK(q.tokens_per_block > 0 && (q.tokens_per_block & (q.tokens_per_block - 1)) == 0,
             "tokens_per_block must be a power of 2 (kvCacheUtils.h:80-82), got %d", q.tokens_per_block);
-        MQ_CHECK(q.max_context_length <= q.max_blocks_per_seq * q.tokens_per_block,
-            "max_context_length %d exceeds the block table (%d x %d)", q.max_context_length, q.max_blocks_per_seq,
-            q.tokens_per_block);
+        MQ_CHECK(windowed || max_kv <= q.max_blocks_per_seq * q.tokens_per_block,
+            "kv length %d exceeds the block table (%d x %d)", max_kv, q.max_blocks_per_seq, q.tokens_per_block);
         MQ_CHECK(q.kv_type == q.act_type || q.kv_type == MI355Q_INT8 || q.kv_type == MI355Q_FP8, "kv cache type %d", q.kv_type);
         if (a.kv_type)
             MQ_CHECK(q.kv_scale_orig_quant, "8-bit kv cache needs kv_scale_orig_quant");
@@ -703,8 +841,10 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     if (q.position_embedding_type == 1 || q.position_embedding_type == 2)
         MQ_CHECK(q.rotary_embedding_dim > 0 && q.rotary_embedding_dim <= q.head_size && q.rotary_embedding_dim % 2 == 0,
             "rotary_embedding_dim %d", q.rotary_embedding_dim);
+    else if (q.position_embedding_type == 3 || q.position_embedding_type == 4) // kALIBI / kALIBI_WITH_SCALE: the scale is in the slopes
+        MQ_CHECK(q.alibi_slopes, "position_embedding_type %d needs alibi_slopes", q.position_embedding_type);
     else
-        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in context (0,1,2)",
+        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in context (0 - 4)",
             q.position_embedding_type);
     const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * q.head_size;
     const size_t tokens = q.remove_padding ? (size_t) q.num_tokens : (size_t) q.batch * q.max_context_length;
@@ -734,7 +874,20 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     // 4 waves x 32 query rows per workgroup.  (8-wave workgroups -- lock-stepped, or the two halves run one segment
     // apart so that a SIMD's two waves alternate matrix and VALU segments -- measured 3-8 % slower: DESIGN.md 4.4)
     const dim3 agrid(q.num_heads, (q.max_context_length + 32 * 4 - 1) / (32 * 4), q.batch);
-#define MQ_CTX_LAUNCH(TT, DD) hipLaunchKernelGGL((ctx_attn_kernel<TT, DD, 4>), agrid, dim3(256), 0, stream, a)
+    const bool bias = a.alibi_slopes != nullptr;
+#define MQ_CTX_LAUNCH2(TT, DD, CC, BB) hipLaunchKernelGGL((ctx_attn_kernel<TT, DD, 4, CC, BB>), agrid, dim3(256), 0, stream, a)
+#define MQ_CTX_LAUNCH(TT, DD)                                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (cached && bias)                                                                                            \
+            MQ_CTX_LAUNCH2(TT, DD, true, true);                                                                        \
+        else if (cached)                                                                                               \
+            MQ_CTX_LAUNCH2(TT, DD, true, false);                                                                       \
+        else if (bias)                                                                                                 \
+            MQ_CTX_LAUNCH2(TT, DD, false, true);                                                                       \
+        else                                                                                                           \
+            MQ_CTX_LAUNCH2(TT, DD, false, false);                                                                      \
+    } while (0)
     if (bf && q.head_size == 128)
         MQ_CTX_LAUNCH(bf16_t, 128);
     else if (bf)
@@ -744,6 +897,7 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     else
         MQ_CTX_LAUNCH(f16_t, 64);
 #undef MQ_CTX_LAUNCH
+#undef MQ_CTX_LAUNCH2
     MQ_HIP(hipGetLastError());
 }
 

@@ -94,6 +94,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     }
     // logits are kept in the log2 domain: exp(x) = exp2(x * log2(e))
     const float sscale = p.score_scale * 1.4426950408889634f * k_deq;
+    // ALiBi (Template.h:1891-1895, :2026): the slot index stands for the time step, as in the reference's loop
+    const bool alibi = p.alibi_slopes != nullptr;
+    float slope2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        slope2[g] = alibi ? T16<T>::to_float(p.alibi_slopes[hq0 + g]) * 1.4426950408889634f : 0.f;
 
     // ---- the new token (registers, un-quantised), handled by wave 0 / slot 0 of the last split
     if (last_split && wave == 0 && ts == 0)
@@ -249,6 +255,17 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
                     for (int e = 0; e < EP; ++e)
                         d = dot2<T>(qp[g][e], kp[e], d);
                     s[g][u] = group_sum<LPT>(d) * sscale;
+                }
+            }
+            if (alibi) // wave-uniform
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const float dist = (float) (t0 + (GEN ? 0 : u * TPW) + ts - tl);
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        s[g][u] = __builtin_fmaf(slope2[g], dist, s[g][u]);
                 }
             }
 
@@ -532,24 +549,12 @@ Plan make_plan(const mi355q_decode_attention_params& q)
         pl.capacity = q.max_blocks_per_seq * q.tokens_per_block;
     }
     // the cyclic map (KVBlockArray ctor :89-93, KVLinearBuffer ctor :291-294)
-    pl.window = q.cyclic_attention_window_size > 0 ? q.cyclic_attention_window_size : pl.capacity;
-    pl.sink = q.sink_token_length;
-    MQ_CHECK(pl.sink >= 0 && pl.sink < pl.window, "sink_token_length %d against a window of %d", pl.sink, pl.window);
-    if (linear)
-    {
-        pl.bubble = 0;
-        pl.cyc_len = pl.window - pl.sink;
-    }
-    else
-    {
-        const int in_last = pl.sink % q.tokens_per_block;
-        pl.bubble = in_last == 0 ? 0 : q.tokens_per_block - in_last;
-        const bool one_more = (q.max_blocks_per_seq - 1) * q.tokens_per_block >= pl.window + pl.bubble;
-        pl.cyc_len = one_more ? pl.window + q.tokens_per_block - pl.sink : pl.window - pl.sink;
-    }
-    MQ_CHECK(pl.sink + pl.bubble + pl.cyc_len <= pl.capacity, "the cyclic cache (sink %d + bubble %d + %d slots) exceeds the %d slots of a sequence",
-        pl.sink, pl.bubble, pl.cyc_len, pl.capacity);
-    MQ_CHECK(pl.window <= pl.capacity, "attention window %d exceeds the %d cache slots of a sequence", pl.window, pl.capacity);
+    const CyclicLayout cl = cyclic_layout(linear, pl.capacity, q.max_blocks_per_seq, q.tokens_per_block,
+        q.cyclic_attention_window_size, q.sink_token_length);
+    pl.window = cl.window;
+    pl.sink = cl.sink;
+    pl.bubble = cl.bubble;
+    pl.cyc_len = cl.cyc_len;
     // without a window every token needs its own slot
     if (q.cyclic_attention_window_size <= 0)
         MQ_CHECK(q.max_seq_len >= 1 && q.max_seq_len <= pl.capacity, "max_seq_len %d exceeds the cache (%d slots per sequence)",
@@ -571,7 +576,7 @@ Plan make_plan(const mi355q_decode_attention_params& q)
     const int g = q.num_heads / q.num_kv_heads;
     const int tpw = 64 / (q.head_size / (16 / pl.kvb));
     const int tpb = linear ? (1 << 30) : q.tokens_per_block;
-    pl.gqa = beams == 1 && gqa_mfma_applies(q);
+    pl.gqa = beams == 1 && !q.alibi_slopes && gqa_mfma_applies(q); // ALiBi: the dot-product kernels add the bias
     // the general form: beams, head sizes / head ratios the grouped kernels are not built for, tiny blocks
     pl.general = !pl.gqa
         && (beams > 1 || !(g == 1 || g == 2 || g == 4 || g == 8) || !(q.head_size == 64 || q.head_size == 128) || tpb < tpw);
@@ -692,8 +697,13 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
     if (q.position_embedding_type == 1 || q.position_embedding_type == 2)
         MQ_CHECK(q.rotary_embedding_dim > 0 && q.rotary_embedding_dim <= q.head_size && q.rotary_embedding_dim % 2 == 0,
             "rotary_embedding_dim %d", q.rotary_embedding_dim);
+    else if (q.position_embedding_type == 3 || q.position_embedding_type == 4) // kALIBI / kALIBI_WITH_SCALE: scale is in the slopes
+    {
+        MQ_CHECK(q.alibi_slopes, "position_embedding_type %d needs alibi_slopes", q.position_embedding_type);
+        a.alibi_slopes = reinterpret_cast<const uint16_t*>(q.alibi_slopes);
+    }
     else
-        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in decode (0,1,2)",
+        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in decode (0 - 4)",
             q.position_embedding_type);
     if (pl.splits > 1)
     {

@@ -41,6 +41,7 @@ struct DecodeArgs
     int q_per_kv, beam_width, indir_stride;
     const int32_t* cache_indir;
     const int32_t* input_lengths;
+    const uint16_t* alibi_slopes; // T [Hq] or null (decode_attn_kernel only): score += slope[h] * (t - tlength), Template.h:2026
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale;
     float score_scale; // 1 / (sqrt(Dh) * q_scaling)
@@ -65,6 +66,35 @@ struct DecodeArgs
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+// the cyclic slot map of a sequence's cache: KVBlockArray ctor (kvCacheUtils.h:71-94), KVLinearBuffer ctor (:277-295)
+struct CyclicLayout
+{
+    int window, sink, bubble, cyc_len;
+};
+inline CyclicLayout cyclic_layout(bool linear, int capacity, int max_blocks, int tokens_per_block, int cyclic_window, int sink)
+{
+    CyclicLayout c{};
+    c.window = cyclic_window > 0 ? cyclic_window : capacity;
+    c.sink = sink;
+    MQ_CHECK(c.sink >= 0 && c.sink < c.window, "sink_token_length %d against a window of %d", c.sink, c.window);
+    if (linear)
+    {
+        c.bubble = 0;
+        c.cyc_len = c.window - c.sink;
+    }
+    else
+    {
+        const int in_last = c.sink % tokens_per_block;
+        c.bubble = in_last == 0 ? 0 : tokens_per_block - in_last;
+        const bool one_more = (max_blocks - 1) * tokens_per_block >= c.window + c.bubble;
+        c.cyc_len = one_more ? c.window + tokens_per_block - c.sink : c.window - c.sink;
+    }
+    MQ_CHECK(c.sink + c.bubble + c.cyc_len <= capacity, "the cyclic cache (sink %d + bubble %d + %d slots) exceeds the %d slots of a sequence",
+        c.sink, c.bubble, c.cyc_len, capacity);
+    MQ_CHECK(c.window <= capacity, "attention window %d exceeds the %d cache slots of a sequence", c.window, capacity);
+    return c;
+}
 
 // KVBlockArray / KVLinearBuffer::getKVTokenIdx (kvCacheUtils.h:109-117, 308-316): the cache slot of token t
 __device__ __forceinline__ int kv_slot(const DecodeArgs& p, int t)

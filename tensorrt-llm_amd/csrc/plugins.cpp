@@ -1210,18 +1210,15 @@ struct GPTAttentionPlugin : PluginBase
         max_seq = d.d[3];
         return static_cast<char*>(outputs[1]) + (size_t) seqBeg * dims_prod(d, 1, d.nbDims) * dtype_size(kvType());
     }
-    // the context phase writes tokens at their own positions: a window shorter than the context (the reference then
-    // masks a sliding window and writes cyclically) and sink tokens are not built there
-    void checkContextWindow(const mi355q_tensor_desc* inDesc, const void* const* inputs, int need) const
+    // the context phase's window: a context longer than cyclic_attention_window_size is masked to the sliding window
+    // and appended cyclically (gptAttentionCommon.cpp:867-873, unfusedAttentionKernels_2_template.h:336-340)
+    void contextWindow(const mi355q_tensor_desc* inDesc, const void* const* inputs, mi355q_context_attention_params& c) const
     {
         const auto& indir = inDesc[getIdx(CACHE_INDIR)].dims;
         if (indir.d[1] != 1)
             MQ_UNSUPPORTED("GPTAttention context: beam_width %d (the context phase runs with beam width 1)", (int) indir.d[1]);
-        const int cyclic_window = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
-        const int sink = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
-        if (sink != 0 || cyclic_window < need)
-            MQ_UNSUPPORTED("GPTAttention context: a context longer than the attention window, or sink tokens, are not built "
-                           "(window %d, sink %d, context length %d)", cyclic_window, sink, need);
+        c.cyclic_attention_window_size = static_cast<const int32_t*>(inputs[getIdx(HOST_MAX_ATTENTION_WINDOW)])[f.layer_idx];
+        c.sink_token_length = static_cast<const int32_t*>(inputs[getIdx(HOST_SINK_TOKEN_LENGTH)])[0];
     }
     void enqueueContext(int seqBeg, int nb, int tokenBeg, int nbTokens, const mi355q_tensor_desc* inDesc,
         const mi355q_tensor_desc* outDesc, const void* const* inputs, void* const* outputs, void* workspace,
@@ -1230,8 +1227,8 @@ struct GPTAttentionPlugin : PluginBase
         MQ_CHECK(seqBeg == 0 && tokenBeg == 0, "context requests come first");
         if (f.mask_type != 1)
             MQ_UNSUPPORTED("GPTAttention context: only the causal mask (AttentionMaskType::CAUSAL = 1) is built, got %d", f.mask_type);
-        if (f.position_embedding_type != 0 && f.position_embedding_type != 1 && f.position_embedding_type != 2)
-            MQ_UNSUPPORTED("GPTAttention context: position_embedding_type %d is not built (0, 1, 2)", f.position_embedding_type);
+        if (f.position_embedding_type < 0 || f.position_embedding_type > 4)
+            MQ_UNSUPPORTED("GPTAttention context: position_embedding_type %d is not built (0 - 4)", f.position_embedding_type);
         const auto& qkvDims = inDesc[getIdx(QKV_TENSOR)].dims;
         int max_len;
         if (f.remove_input_padding)
@@ -1247,7 +1244,7 @@ struct GPTAttentionPlugin : PluginBase
         mi355q_context_attention_params c = contextParams(nb, 0, max_len, nbTokens);
         if (f.use_cache)
         {
-            checkContextWindow(inDesc, inputs, max_len);
+            contextWindow(inDesc, inputs, c);
             if (f.paged_kv_cache)
             {
                 c.block_pointers = blockPointers(inDesc, inputs, seqBeg, max_blocks);
@@ -1255,11 +1252,20 @@ struct GPTAttentionPlugin : PluginBase
             }
             else
                 c.kv_linear_buffer = linearCache(outDesc, outputs, seqBeg, c.linear_max_seq_len);
+            if (f.use_paged_context_fmha) // chunked context (:825-864): the earlier chunks are read back from the cache
+            {
+                MQ_CHECK(f.paged_kv_cache, "use_paged_context_fmha needs paged_kv_cache");
+                const int32_t* kvl = static_cast<const int32_t*>(inputs[getIdx(HOST_PAST_KEY_VALUE_LENGTHS)]) + seqBeg;
+                c.sequence_lengths = static_cast<const int32_t*>(inputs[getIdx(SEQUENCE_LENGTH)]) + seqBeg;
+                c.max_kv_length = *std::max_element(kvl, kvl + nb); // max_context_kv_len, gptAttentionPlugin.cpp:558-563
+            }
             if (hasKvQuant())
                 c.kv_scale_orig_quant = static_cast<const float*>(inputs[getIdx(KV_CACHE_QUANTIZATION_SCALE)]);
         }
         c.qkv = inputs[getIdx(QKV_TENSOR)];
         c.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
+        if (f.position_embedding_type == 3 || f.position_embedding_type == 4)
+            c.alibi_slopes = inputs[getIdx(ALIBI_SLOPES)];
         c.out = outputs[0];
         c.context_lengths = static_cast<const int32_t*>(inputs[getIdx(CONTEXT_LENGTHS)]) + seqBeg;
         c.workspace = workspace;
@@ -1299,6 +1305,8 @@ struct GPTAttentionPlugin : PluginBase
         p.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
         p.out = out;
         p.sequence_lengths = static_cast<const int32_t*>(inputs[getIdx(SEQUENCE_LENGTH)]) + seqBeg;
+        if (f.position_embedding_type == 3 || f.position_embedding_type == 4)
+            p.alibi_slopes = inputs[getIdx(ALIBI_SLOPES)];
         p.block_pointers = bp;
         if (hasKvQuant())
         {

@@ -90,6 +90,7 @@ class DecodeAttentionParams(C.Structure):
         ("beam_width", C.c_int32), ("max_attention_window_size", C.c_int32),
         ("cache_indirection", C.c_void_p), ("input_lengths", C.c_void_p),
         ("kv_linear_buffer", C.c_void_p), ("linear_max_seq_len", C.c_int32),
+        ("alibi_slopes", C.c_void_p),
     ]
 
 
@@ -108,6 +109,9 @@ class ContextAttentionParams(C.Structure):
         ("rotary_embedding_scale", C.c_float), ("rotary_embedding_max_positions", C.c_int32),
         ("q_scaling", C.c_float),
         ("kv_linear_buffer", C.c_void_p), ("linear_max_seq_len", C.c_int32),
+        ("sequence_lengths", C.c_void_p), ("max_kv_length", C.c_int32),
+        ("cyclic_attention_window_size", C.c_int32), ("sink_token_length", C.c_int32),
+        ("alibi_slopes", C.c_void_p),
     ]
 
 

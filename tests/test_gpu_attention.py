@@ -40,14 +40,14 @@ def build_case(B, Hq, Hkv, D, seq_lens, tpb, dtype, kv_dtype, seed=42, max_seq=N
 
 
 def run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, tpb, dtype, kv_dtype, dev, rope=None, bias=None, kv_scale=1.0,
-               remove_padding=False, num_layers=1, layer_idx=0):
+               remove_padding=False, num_layers=1, layer_idx=0, alibi=None, pe=None):
     B = qkv.shape[0]
     qm = 0
     if kv_dtype == torch.int8:
         qm = 1 << 6
     elif kv_dtype == torch.float8_e4m3fn:
         qm = 1 << 7
-    pe = {None: 0, "gptj": 1, "neox": 2}[rope]
+    pe = {None: 0, "gptj": 1, "neox": 2}[rope] if pe is None else pe
     plg = F.make_gpt_attention_plugin(
         num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="float16" if dtype == torch.float16 else "bfloat16",
         layer_idx=layer_idx, position_embedding_type=pe, rotary_embedding_dim=D if rope else 0,
@@ -78,6 +78,8 @@ def run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, tpb, dtype, kv_dtype, dev, rope
         kwargs["host_context_lengths"] = seq - 1
     if bias is not None:
         kwargs["qkv_bias"] = bias.to(dev)
+    if alibi is not None:
+        kwargs["alibi_slopes"] = alibi.to(dev)
     out = F.gpt_attention(plg, **kwargs)
     torch.cuda.synchronize()
     return out.reshape(B, -1).cpu(), pool.cpu()
@@ -124,6 +126,29 @@ def test_decode_8bit_cache(cuda, dtype, kv_dtype, Hq, Hkv, D, tpb):
 def test_decode_rope_and_bias(cuda, dtype, rope):
     check(2, 8, 2, 128, [77, 300], 64, dtype, dtype, cuda, rope=rope, with_bias=True)
     check(2, 4, 4, 64, [77, 300], 64, dtype, torch.int8, cuda, rope=rope)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D,kv_dtype", [(8, 8, 64, None), (8, 8, 128, torch.int8), (16, 2, 128, None), (12, 4, 32, None)])
+def test_decode_alibi(cuda, dtype, Hq, Hkv, D, kv_dtype):
+    # kALIBI (3) / kALIBI_WITH_SCALE (4): score += slope[h] * (t - tlength) (Template.h:2026), slopes in T, any head
+    # ratio (GQA 8 takes the dot-product kernel instead of the MFMA one; 12:4 at d32 the general form); the reference's
+    # test grid has bloom / falcon style ALiBi in test_gpt_attention.py only at generation ("parity unpinned" vs its
+    # goldens: the HF models are not loadable here)
+    kv_dtype = kv_dtype or dtype
+    seq_lens = [300, 17]
+    for pe, scale in ((3, 1.0), (4, 1.0 / np.sqrt(D))):
+        slopes = (torch.tensor([2.0 ** (-8.0 * (i + 1) / Hq) for i in range(Hq)]) * scale).to(dtype)
+        cache, qkv, kv_scale = build_case(2, Hq, Hkv, D, seq_lens, 64, dtype, kv_dtype, seed=pe)
+        out, pool_after = run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, 64, dtype, kv_dtype, cuda, kv_scale=kv_scale,
+                                     alibi=slopes, pe=pe)
+        ref = oracle.decode_attention(qkv, cache, seq_lens, Hq, Hkv, D, kv_scale_orig_quant=1.0 / kv_scale,
+                                      kv_scale_quant_orig=kv_scale, alibi_slopes=slopes)
+        noal = oracle.decode_attention(qkv, cache, seq_lens, Hq, Hkv, D, kv_scale_orig_quant=1.0 / kv_scale,
+                                       kv_scale_quant_orig=kv_scale, update_cache=False)
+        assert (out.float() - ref.float()).abs().max().item() <= ATOL[dtype]
+        assert (noal.float() - ref.float()).abs().max().item() > 10 * ATOL[dtype]  # the bias matters in this case
+        assert torch.equal(pool_after.view(torch.uint8), cache.pool.view(torch.uint8))
 
 
 def test_decode_edge_lengths(cuda):

@@ -156,6 +156,24 @@ def test_context_edge_lengths(cuda):
         check(lens, 8, 1, 64, 32, torch.bfloat16, torch.int8, cuda)
 
 
+def test_context_large_logits(cuda):
+    # scores of +-30: the running maximum must be the column's true maximum (the 4 lanes that share a query column
+    # all-reduce it), else the fp16 probabilities overflow.  Regression test for the swap-based all-reduce.
+    for dtype in (torch.float16, torch.bfloat16):
+        for D in (64, 128):
+            lens = [150, 64]
+            g = torch.Generator().manual_seed(5)
+            rows = [(torch.randn(n, 3 * 4 * D, generator=g) * 3.0).to(dtype) for n in lens]
+            cache = oracle.PagedKVCache(2, 4, D, 200, 64, dtype)
+            pool = cache.pool.to(cuda)
+            plg = make_plugin(4, 4, D, dtype, dtype, 64, None, None, True)
+            outs, _ = run_context(plg, rows, cache, pool, cuda, 1.0, True)
+            refs = oracle.context_attention(rows, lens, 4, 4, D, cache=cache)
+            for o, r in zip(outs, refs):
+                assert torch.isfinite(o.float()).all()
+                assert (o.float() - r.float()).abs().max().item() <= ATOL[dtype] * 8  # outputs of magnitude ~8
+
+
 def test_context_remove_padding_and_layer_offset(cuda):
     check([9, 200, 70], 4, 2, 128, 64, torch.float16, torch.float16, cuda, remove_padding=True, num_layers=3, layer_idx=2)
     check([5, 1, 131], 8, 8, 64, 64, torch.bfloat16, torch.float8_e4m3fn, cuda, remove_padding=True, rope="neox")
