@@ -94,6 +94,7 @@ struct CtxArgs
     int mask_window;          // sliding window: key t is visible to the query at position a iff a - mask_window <= t <= a
     int kv_window, sink, bubble, cyc_len; // cache slot map of the append (kvCacheUtils.h:71-117); identity without a window
     const uint16_t* alibi_slopes;         // T [Hq] or null: score += slope[h] * (t - a)
+    int dh_pad; // row length of `proc`: head_size, or the 64 / 128 it is padded to (zeros) for the attention kernel
 };
 
 __device__ __forceinline__ int ctx_kv_slot(const CtxArgs& p, int t)
@@ -200,11 +201,14 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         }
         __syncthreads();
     }
-    // processed rows, head-major: vector v of the row goes to proc[(v' * rows + row) * D] with q heads first
-    for (int i = threadIdx.x; i < hidden / 2; i += 256)
+    // processed rows, head-major: vector v of the row goes to proc[(v' * rows + row) * dh_pad] with q heads first;
+    // a head size the attention kernel is not built for is padded with zeros to the next one that is
+    const int DP = p.dh_pad;
+    for (int i = threadIdx.x; i < (Hq + 2 * Hkv) * DP / 2; i += 256)
     {
-        const int e = 2 * i, vec = e / D, d = e % D;
-        *reinterpret_cast<uint32_t*>(p.proc + ((size_t) vec * p.rows + row) * D + d) = pack2<T>(xs[e], xs[e + 1]);
+        const int e = 2 * i, vec = e / DP, d = e % DP;
+        const uint32_t w = d < D ? pack2<T>(xs[vec * D + d], xs[vec * D + d + 1]) : 0u;
+        *reinterpret_cast<uint32_t*>(p.proc + ((size_t) vec * p.rows + row) * DP + d) = w;
     }
     // cache append at the slot of position pos: block [Hkv][tokens_per_block][Dh]
     if (ctx_has_cache(p) && ctx_keeps(p, pos, past + len))
@@ -720,11 +724,13 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         const int qr = q0 + 16 * qt + lr;
         if (qr < len)
         {
-            uint16_t* orow = p.out + (row0 + qr) * (size_t) (p.num_heads * DH) + (size_t) h * DH;
+            const int hs = p.head_size; // <= DH: columns past it are the zero padding of `proc`
+            uint16_t* orow = p.out + (row0 + qr) * (size_t) (p.num_heads * hs) + (size_t) h * hs;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * lq) = make_uint2(
-                    pack2<T>(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack2<T>(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+                if (16 * dt + 4 * lq < hs)
+                    *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * lq) = make_uint2(
+                        pack2<T>(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack2<T>(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
         }
     }
 }
@@ -741,7 +747,7 @@ int ctx_ilog2(int x)
 
 size_t context_attention_workspace_size(const mi355q_context_attention_params& q)
 {
-    const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * q.head_size;
+    const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * (q.head_size <= 64 ? 64 : 128); // padded rows
     const size_t tokens = q.remove_padding ? (size_t) q.num_tokens : (size_t) q.batch * q.max_context_length;
     return tokens * hidden * 2 + ((size_t) q.batch * sizeof(int32_t) + 255) / 256 * 256;
 }
@@ -751,7 +757,11 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     MQ_CHECK(q.act_type == MI355Q_HALF || q.act_type == MI355Q_BF16, "act_type %d", q.act_type);
     MQ_CHECK(q.qkv && q.out && q.context_lengths, "null tensor");
     MQ_CHECK(q.batch >= 0 && q.num_heads > 0 && q.num_kv_heads > 0 && q.num_heads % q.num_kv_heads == 0, "bad sizes");
-    MQ_CHECK(q.head_size == 64 || q.head_size == 128, "context attention: head_size %d not built (64, 128)", q.head_size);
+    // 64 / 128 run as they are; other multiples of 8 up to 128 are zero-padded to the next of the two in the workspace
+    // (the reference's context FMHA is built for 32, 40, 64, 80, 128, 160, 256; its unfused path takes any size)
+    MQ_CHECK(q.head_size >= 8 && q.head_size <= 128 && q.head_size % 8 == 0,
+        "context attention: head_size %d not built (multiples of 8 up to 128)", q.head_size);
+    const int dh_pad = q.head_size <= 64 ? 64 : 128;
     if (q.batch == 0 || q.max_context_length == 0)
         return;
     const size_t need = context_attention_workspace_size(q);
@@ -847,13 +857,17 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
         MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in context (0 - 4)",
             q.position_embedding_type);
     const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * q.head_size;
+    const size_t hidden_pad = (size_t) (q.num_heads + 2 * q.num_kv_heads) * dh_pad;
     const size_t tokens = q.remove_padding ? (size_t) q.num_tokens : (size_t) q.batch * q.max_context_length;
     MQ_CHECK(tokens > 0 && tokens < (1u << 31), "token rows %zu", tokens);
     a.rows = (int) tokens;
+    a.dh_pad = dh_pad;
     a.proc = reinterpret_cast<uint16_t*>(q.workspace);
+    if (dh_pad != q.head_size)
+        MQ_CHECK(!cached, "chunked context with head_size %d is not built (the kernel streams cache rows of 64 / 128)", q.head_size);
     if (q.remove_padding)
     {
-        int32_t* offs = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(q.workspace) + tokens * hidden * 2);
+        int32_t* offs = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(q.workspace) + tokens * hidden_pad * 2);
         hipLaunchKernelGGL(ctx_offsets_kernel, dim3(1), dim3(64), 0, stream, q.context_lengths, offs, q.batch);
         a.offsets = offs;
     }
@@ -861,8 +875,9 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     const dim3 pgrid(q.max_context_length, q.batch);
     const size_t plds = (hidden + q.head_size) * sizeof(float);
     MQ_CHECK(plds <= 64 * 1024, "qkv hidden size %zu too large for the prepare kernel", hidden);
-    const bool fast = q.position_embedding_type == 0 || q.position_embedding_type == 1
-        || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size);
+    const bool fast = dh_pad == q.head_size
+        && (q.position_embedding_type == 0 || q.position_embedding_type == 1 || q.position_embedding_type == 3
+            || q.position_embedding_type == 4 || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size));
     if (fast && bf)
         hipLaunchKernelGGL(ctx_prepare_fast_kernel<bf16_t>, pgrid, dim3(256), 0, stream, a);
     else if (fast)
@@ -888,11 +903,11 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
         else                                                                                                           \
             MQ_CTX_LAUNCH2(TT, DD, false, false);                                                                      \
     } while (0)
-    if (bf && q.head_size == 128)
+    if (bf && dh_pad == 128)
         MQ_CTX_LAUNCH(bf16_t, 128);
     else if (bf)
         MQ_CTX_LAUNCH(bf16_t, 64);
-    else if (q.head_size == 128)
+    else if (dh_pad == 128)
         MQ_CTX_LAUNCH(f16_t, 128);
     else
         MQ_CTX_LAUNCH(f16_t, 64);

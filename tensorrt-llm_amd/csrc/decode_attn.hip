@@ -30,9 +30,10 @@ namespace
 // GEN = the general form: one workgroup per QUERY head (G = 1; any q / kv head ratio), every lane resolves its own
 // token's block pointer, so beams (cache_indirection, decoderMaskedMultiheadAttentionTemplate.h:1873-1879, 2076, 2441)
 // and tiles that straddle blocks work; the kv group's first query head appends the new token.
-template <typename T, int KVT, int DH, int G, int U, bool GEN = false>
+template <typename T, int KVT, int DH, int G, int U, bool GEN = false, bool PAD = false>
 __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
 {
+    static_assert(!PAD || GEN, "padded head sizes run in the general form");
     static_assert(!GEN || (G == 1 && U == 1), "the general form serves one query head per workgroup");
     constexpr int KVB = KVT == 0 ? 2 : 1;  // bytes per cache element
     constexpr int E = 16 / KVB;            // cache elements per lane per load
@@ -68,10 +69,14 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     const bool last_split = split == p.splits - 1;
     const bool appends = !GEN || hg % p.q_per_kv == 0;
 
-    stage_new_token<T, DH, G>(p, b, hq0, hk, tl, smem);
+    stage_new_token<T, DH, G, PAD>(p, b, hq0, hk, tl, smem);
 
     const int ts = lane / LPT;  // token slot inside a wave-load
     const int ch = lane % LPT;  // 16-byte chunk of the row
+    // PAD (head sizes that are not a power of two, run as the next one): a cache row is hs elements, lanes whose chunk
+    // lies past it hold zeros and touch no memory
+    const int hs = PAD ? p.hs : DH;
+    const bool ch_live = !PAD || ch * E < hs;
     const float k_deq = KVT ? p.kv_scale_quant_orig[0] : 1.f;
 
     // q chunk of this lane, packed 16-bit pairs (exact: q was rounded to T above)
@@ -135,10 +140,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     const bool wrapped = slot < kv_len;
     auto append_new_token = [&]()
     {
-        if (wave == 0 && ts == 0 && appends)
+        if (wave == 0 && ts == 0 && appends && ch_live)
         {
             const int blk = slot >> p.tpb_log2;
-            const size_t row = ((size_t) hk * p.head_tokens + (slot & (tpb - 1))) * DH * KVB + (size_t) ch * 16;
+            const size_t row = ((size_t) hk * p.head_tokens + (slot & (tpb - 1))) * hs * KVB + (size_t) ch * 16;
             uint4 kw, vw;
             if constexpr (KVT == 0)
             {
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
         const int tps = (ntiles + p.splits - 1) / p.splits;
         const int tile_end = min(ntiles, (split + 1) * tps);
         writes_after_loop = wrapped && (slot / TILE) / tps == split;
-        const size_t head_off = (size_t) hk * p.head_tokens * DH * KVB + (size_t) ch * 16;
+        const size_t head_off = (size_t) hk * p.head_tokens * hs * KVB + (size_t) ch * 16;
         // beams: tokens before beam0_context_length come from beam 0 of the batch entry, later ones from the beam
         // cache_indir names; with a wrapped cyclic cache the context may be overwritten: 0 (Template.h:1497-1498)
         const int beam_w = GEN ? max(p.beam_width, 1) : 1;
@@ -196,11 +201,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
                 valid[0] = t < kv_len;
                 kreg[0] = make_uint4(0, 0, 0, 0);
                 vreg[0] = make_uint4(0, 0, 0, 0);
-                if (valid[0])
+                if (valid[0] && ch_live)
                 {
                     const int seq = beam_w > 1 ? seq0 + (t < beam0_ctx ? 0 : indir[t]) : b;
                     const int blk = t >> p.tpb_log2;
-                    const size_t off = head_off + (size_t) (t & (tpb - 1)) * DH * KVB;
+                    const size_t off = head_off + (size_t) (t & (tpb - 1)) * hs * KVB;
                     kreg[0] = *reinterpret_cast<const uint4*>(kv_block_ptr(p, seq, 0, blk) + off);
                     vreg[0] = *reinterpret_cast<const uint4*>(kv_block_ptr(p, seq, 1, blk) + off);
                 }
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
         }
     }
     __syncthreads();
-    finish_states<T, G, DH, NW * 64, NW>(p, b * heads_in_grid + hg, (size_t) b * Hq + hq0, split, red);
+    finish_states<T, G, DH, NW * 64, NW, PAD>(p, b * heads_in_grid + hg, (size_t) b * Hq + hq0, split, red);
 }
 
 int ilog2(int x)
@@ -484,19 +489,26 @@ template <typename T, int KVT, int DH>
 void launch_general(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStream_t stream)
 {
     const int grid = q.batch * q.num_heads * a.splits;
-    hipLaunchKernelGGL((decode_attn_kernel<T, KVT, DH, 1, 1, true>), dim3(grid), dim3(NW * 64), 0, stream, a);
+    if (q.head_size == DH)
+        hipLaunchKernelGGL((decode_attn_kernel<T, KVT, DH, 1, 1, true>), dim3(grid), dim3(NW * 64), 0, stream, a);
+    else // 48, 80, 96, 104, 112, 144, 160, 192, 224 ... (decoderMaskedMultiheadAttention.cu dispatches on 13 sizes)
+        hipLaunchKernelGGL((decode_attn_kernel<T, KVT, DH, 1, 1, true, true>), dim3(grid), dim3(NW * 64), 0, stream, a);
+}
+
+int padded_head_size(int hs)
+{
+    return hs <= 32 ? 32 : (hs <= 64 ? 64 : (hs <= 128 ? 128 : 256));
 }
 
 template <typename T, int KVT>
 void dispatch_general_dh(const mi355q_decode_attention_params& q, const DecodeArgs& a, hipStream_t s)
 {
-    switch (q.head_size)
+    switch (padded_head_size(q.head_size))
     {
     case 32: launch_general<T, KVT, 32>(q, a, s); break;
     case 64: launch_general<T, KVT, 64>(q, a, s); break;
     case 128: launch_general<T, KVT, 128>(q, a, s); break;
-    case 256: launch_general<T, KVT, 256>(q, a, s); break;
-    default: MQ_UNSUPPORTED("decode attention: head_size %d not built (32, 64, 128, 256)", q.head_size);
+    default: launch_general<T, KVT, 256>(q, a, s); break;
     }
 }
 
@@ -571,10 +583,13 @@ Plan make_plan(const mi355q_decode_attention_params& q)
             std::min(q.max_seq_len - 1, pl.window));
     }
     pl.kvb = q.kv_type == q.act_type ? 2 : 1;
-    MQ_CHECK(q.head_size == 32 || q.head_size == 64 || q.head_size == 128 || q.head_size == 256,
-        "head_size %d not built (32, 64, 128, 256)", q.head_size);
+    // a lane holds 16 bytes of a cache row: head sizes in multiples of 8 (16-bit cache) / 16 (8-bit cache), up to 256;
+    // sizes that are not 32 / 64 / 128 / 256 run padded to the next of those in the general form
+    MQ_CHECK(q.head_size >= 16 && q.head_size <= 256 && q.head_size % (16 / pl.kvb) == 0,
+        "head_size %d not built (multiples of %d up to 256)", q.head_size, 16 / pl.kvb);
+    const int dhp = padded_head_size(q.head_size);
     const int g = q.num_heads / q.num_kv_heads;
-    const int tpw = 64 / (q.head_size / (16 / pl.kvb));
+    const int tpw = 64 / (dhp / (16 / pl.kvb));
     const int tpb = linear ? (1 << 30) : q.tokens_per_block;
     pl.gqa = beams == 1 && !q.alibi_slopes && gqa_mfma_applies(q); // ALiBi: the dot-product kernels add the bias
     // the general form: beams, head sizes / head ratios the grouped kernels are not built for, tiny blocks
@@ -609,7 +624,7 @@ namespace
 size_t group_floats(const mi355q_decode_attention_params& q, const Plan& pl)
 {
     const size_t g = pl.general ? 1 : (size_t) (q.num_heads / q.num_kv_heads);
-    return ((size_t) pl.splits * g * (q.head_size + PART_PAD) + 31) / 32 * 32;
+    return ((size_t) pl.splits * g * (padded_head_size(q.head_size) + PART_PAD) + 31) / 32 * 32;
 }
 // bytes of the split-KV area of one call
 size_t partials_bytes(const mi355q_decode_attention_params& q, const Plan& pl)
@@ -627,7 +642,7 @@ size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
                                                : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
     const size_t groups = (size_t) q.batch * q.num_heads; // the general form has one group per query head
     // records + the per-group padding to a line
-    return rows * q.num_heads * (q.head_size + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);
+    return rows * q.num_heads * (padded_head_size(q.head_size) + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);
 }
 
 #ifdef MI355Q_LAB
@@ -676,6 +691,7 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
     a.tpb_log2 = linear ? 30 : ilog2(q.tokens_per_block); // one "block" holds the whole sequence of a linear cache
     a.head_tokens = linear ? q.linear_max_seq_len : q.tokens_per_block;
     a.linear_base = static_cast<const char*>(q.kv_linear_buffer);
+    a.hs = q.head_size;
     a.linear_plane_bytes = linear ? (size_t) q.num_kv_heads * q.linear_max_seq_len * q.head_size * pl.kvb : 0;
     a.kv_window = pl.window;
     a.sink = pl.sink;

@@ -41,6 +41,7 @@ struct DecodeArgs
     int q_per_kv, beam_width, indir_stride;
     const int32_t* cache_indir;
     const int32_t* input_lengths;
+    int hs;                       // the head size in memory when a kernel runs a head padded to its DH (PAD form): hs <= DH
     const uint16_t* alibi_slopes; // T [Hq] or null (decode_attn_kernel only): score += slope[h] * (t - tlength), Template.h:2026
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale;
@@ -191,19 +192,23 @@ struct NewTokenRegs
     uint4 x[TRIPS], bias[TRIPS];
 };
 
-template <typename T, int DH, int G>
+// PAD: the head occupies hs = p.hs <= DH elements in memory; the registers / LDS keep the DH layout, elements past hs
+// are zero.
+template <typename T, int DH, int G, bool PAD = false>
 __device__ __forceinline__ void issue_new_token(const DecodeArgs& p, int b, int hq0, int hk, NewTokenRegs<G, DH>& r)
 {
     const int tid = threadIdx.x;
     const int Hq = p.num_heads, Hkv = p.num_kv_heads;
-    const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * DH;
+    const int hs = PAD ? p.hs : DH;
+    const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * hs;
     const uint16_t* bias = p.qkv_bias ? reinterpret_cast<const uint16_t*>(p.qkv_bias) : qkv;
 #pragma unroll
     for (int t = 0; t < NewTokenRegs<G, DH>::TRIPS; ++t)
     {
         const int v = min(tid + t * NW * 64, NewTokenRegs<G, DH>::NV - 1); // past the end: a valid vector, not stored
-        const int vec = (v * 8) / DH, d = (v * 8) % DH;
-        const int off = vec < G ? (hq0 + vec) * DH + d : (vec == G ? (Hq + hk) * DH + d : (Hq + Hkv + hk) * DH + d);
+        const int vec = (v * 8) / DH;
+        const int d = PAD ? min((v * 8) % DH, hs - 8) : (v * 8) % DH; // past the head: a valid vector, zeroed when staged
+        const int off = vec < G ? (hq0 + vec) * hs + d : (vec == G ? (Hq + hk) * hs + d : (Hq + Hkv + hk) * hs + d);
         r.x[t] = *reinterpret_cast<const uint4*>(qkv + off);
         r.bias[t] = *reinterpret_cast<const uint4*>(bias + off);
     }
@@ -223,7 +228,7 @@ __device__ __forceinline__ float rope_early_pow(const DecodeArgs& p)
 // RoPE in fp32 (decoderMaskedMultiheadAttentionTemplate.h:1391-1527).  smem: [(G + 2) * DH] floats
 // = q[G][DH], k[DH], v[DH].  Ends with a barrier.  The cos / sin table is built before the token's registers are
 // touched, i.e. while their loads are still in flight.
-template <typename T, int DH, int G>
+template <typename T, int DH, int G, bool PAD = false>
 __device__ __forceinline__ void stage_new_token(
     const DecodeArgs& p, const NewTokenRegs<G, DH>& r, int tl, float* smem, float early_pow)
 {
@@ -277,6 +282,8 @@ __device__ __forceinline__ void stage_new_token(
                         const float bb = (j & 1) ? T16<T>::hi(bw[j >> 1]) : T16<T>::lo(bw[j >> 1]);
                         x = T16<T>::to_float(T16<T>::from_float(x + bb));
                     }
+                    if (PAD && (v * 8) % DH >= p.hs)
+                        x = 0.f;
                     smem[v * 8 + j] = x;
                 }
             }
@@ -300,12 +307,12 @@ __device__ __forceinline__ void stage_new_token(
     }
 }
 
-template <typename T, int DH, int G>
+template <typename T, int DH, int G, bool PAD = false>
 __device__ __forceinline__ void stage_new_token(const DecodeArgs& p, int b, int hq0, int hk, int tl, float* smem)
 {
     NewTokenRegs<G, DH> r;
-    issue_new_token<T, DH, G>(p, b, hq0, hk, r);
-    stage_new_token<T, DH, G>(p, r, tl, smem, rope_early_pow(p));
+    issue_new_token<T, DH, G, PAD>(p, b, hq0, hk, r);
+    stage_new_token<T, DH, G, PAD>(p, r, tl, smem, rope_early_pow(p));
 }
 
 typedef __attribute__((address_space(1))) uint32_t dec_gu32;
@@ -335,12 +342,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dec_rsrc(const void* p, size_t
 // whose add came last".  The arrival word comes from arrival_ring.hip (zero at launch, one per 128-byte line, put
 // back to zero by the last arrival's own wrapping increment -- one round trip, no reset pass, graph replay safe).
 // `red` is reused as scratch (>= 1 + G * 65 floats).
-template <typename T, int G, int DH, int THREADS, int NSTATES>
+template <typename T, int G, int DH, int THREADS, int NSTATES, bool PAD = false>
 __device__ __forceinline__ void finish_states(const DecodeArgs& p, int group, size_t out_head0, int split, float* red)
 {
     constexpr int RS = DH + 2;           // LDS row stride
     constexpr int REC = DH + PART_PAD;   // global record stride (floats)
     const int tid = threadIdx.x;
+    const int hs = PAD ? p.hs : DH;      // output row: hs elements per head (columns past hs are padding, not stored)
     const size_t grp_bytes = (size_t) p.group_floats * sizeof(float);
     const __amdgpu_buffer_rsrc_t grp
         = dec_rsrc(p.partials + (size_t) group * p.group_floats, p.splits > 1 ? grp_bytes : 0);
@@ -368,7 +376,8 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int group, si
             // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2285-2290)
             const float inv = 1.f / (ll + 1e-6f);
             const uint2 v = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * DH + d) = v;
+            if (!PAD || d < hs)
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * hs + d) = v;
         }
         else
         {
@@ -434,7 +443,8 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int group, si
             }
             const float inv = 1.f / (ll + 1e-6f); // decoderMaskedMultiheadAttentionTemplate.h:2771-2777
             const uint2 w = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * DH + d) = w;
+            if (!PAD || d < hs)
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * hs + d) = w;
         }
         MQ_STAMP(p, 9);
         return;
@@ -486,7 +496,8 @@ __device__ __forceinline__ void finish_states(const DecodeArgs& p, int group, si
         // inv_sum = 1 / (sum + 1e-6)  (decoderMaskedMultiheadAttentionTemplate.h:2771-2777)
         const float inv = 1.f / (l_s[g] + 1e-6f);
         const uint2 v = make_uint2(pack2<T>(o[0] * inv, o[1] * inv), pack2<T>(o[2] * inv, o[3] * inv));
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * DH + d) = v;
+        if (!PAD || d < hs)
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (out_head0 + g) * hs + d) = v;
     }
 }
 

@@ -151,6 +151,17 @@ def test_decode_alibi(cuda, dtype, Hq, Hkv, D, kv_dtype):
         assert torch.equal(pool_after.view(torch.uint8), cache.pool.view(torch.uint8))
 
 
+@pytest.mark.parametrize("D", [48, 80, 96, 104, 112, 144, 160, 192, 224])
+def test_decode_other_head_sizes(cuda, D):
+    # the head sizes decoderMaskedMultiheadAttention.cu dispatches on besides 32 / 64 / 128 / 256: run padded to the next
+    # power of two in the general kernel (cache rows and the qkv / output rows keep their real size)
+    check(2, 4, 2, D, [150, 9], 64, torch.float16, torch.float16, cuda)
+    check(2, 6, 6, D, [70, 131], 16, torch.bfloat16, torch.bfloat16, cuda, rope="neox" if D % 16 == 0 else "gptj", with_bias=True)
+    if D % 16 == 0:  # an 8-bit cache row is read 16 bytes per lane
+        check(2, 8, 1, D, [300, 33], 32, torch.float16, torch.int8, cuda)
+        check(1, 4, 4, D, [2100], 64, torch.bfloat16, torch.float8_e4m3fn, cuda)  # split-KV merge of padded records
+
+
 def test_decode_edge_lengths(cuda):
     # first generated token (no cached keys), exact block boundaries, one past a boundary
     for sl in ([1, 1], [64, 65], [128, 129], [2, 257]):

@@ -174,6 +174,16 @@ def test_context_large_logits(cuda):
                 assert (o.float() - r.float()).abs().max().item() <= ATOL[dtype] * 8  # outputs of magnitude ~8
 
 
+@pytest.mark.parametrize("D", [32, 48, 80, 96, 112])
+def test_context_other_head_sizes(cuda, D):
+    # head sizes besides 64 / 128: zero-padded to the next of the two in the workspace (the cache and the output keep the
+    # real size); RoPE (generic prepare kernel), bias, 16-bit and 8-bit caches
+    check([130, 37], 4, 2, D, 64, torch.float16, torch.float16, cuda, rope="neox", with_bias=True)
+    check([70, 200], 6, 6, D, 16, torch.bfloat16, torch.bfloat16, cuda, remove_padding=True)
+    if D % 16 == 0:
+        check([166, 41], 8, 1, D, 32, torch.float16, torch.int8, cuda, rope="gptj")
+
+
 def test_context_remove_padding_and_layer_offset(cuda):
     check([9, 200, 70], 4, 2, 128, 64, torch.float16, torch.float16, cuda, remove_padding=True, num_layers=3, layer_idx=2)
     check([5, 1, 131], 8, 8, 64, 64, torch.bfloat16, torch.float8_e4m3fn, cuda, remove_padding=True, rope="neox")
@@ -283,7 +293,7 @@ def test_context_c_abi_without_cache_and_errors(cuda):
     assert L.lib().mi355q_context_attention(C.byref(p), None) != 0
     assert b"workspace" in L.lib().mi355q_last_error()
     p.workspace_bytes = need
-    p.head_size = 80
+    p.head_size = 160
     assert L.lib().mi355q_context_attention(C.byref(p), None) != 0
 
 
