@@ -366,19 +366,24 @@ def bench_gated_act(dev, steps, tokens=4096, inter=13824, sets=6):
     return out
 
 
-def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16"):
+def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16", past=0):
     """8f rank 1: context (prefill) attention, Llama-2-7B heads: bias-less RoPE + paged KV append + causal
-    attention; flops counted on the causal half (2 * 2 * S^2/2 * D per head)."""
+    attention; flops counted on the causal half (2 * 2 * S^2/2 * D per head).  past > 0: chunked context -- the
+    last S - past tokens of the sequence attend to all S keys through the paged cache."""
     from mi355q import _lib as L
     import ctypes as C
     torch.manual_seed(0)
     dt = torch.bfloat16
-    qkv = (torch.randn(B, S, (H + 2 * Hkv) * D, device=dev) * 0.5).to(dt)
-    out = torch.empty(B, S, H * D, dtype=dt, device=dev)
-    cl = torch.full((B,), S, dtype=torch.int32, device=dev)
+    Sq = S - past                      # this call's tokens
+    qkv = (torch.randn(B, Sq, (H + 2 * Hkv) * D, device=dev) * 0.5).to(dt)
+    out = torch.empty(B, Sq, H * D, dtype=dt, device=dev)
+    cl = torch.full((B,), Sq, dtype=torch.int32, device=dev)
+    sl = torch.full((B,), S, dtype=torch.int32, device=dev)
     kvdt = {"bf16": dt, "int8": torch.int8, "fp8": torch.float8_e4m3fn}[kv]
     nblk = B * (S // tpb)
     pool = torch.zeros(nblk, 2, Hkv, tpb, D, dtype=kvdt, device=dev)
+    if past:
+        pool.copy_((torch.randn(pool.shape, device=dev) * 0.5).to(kvdt))
     be = Hkv * tpb * D * pool.element_size()
     ids = torch.randperm(nblk).reshape(B, S // tpb)
     ptrs = (torch.stack([ids * 2 * be, ids * 2 * be + be], 1) + pool.data_ptr()).to(torch.int64).to(dev)
@@ -388,7 +393,9 @@ def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64
     p.kv_scale_orig_quant = sc.data_ptr()
     p.batch, p.num_heads, p.num_kv_heads, p.head_size = B, H, Hkv, D
     p.max_blocks_per_seq, p.tokens_per_block = S // tpb, tpb
-    p.max_context_length, p.num_tokens, p.remove_padding = S, B * S, 0
+    p.max_context_length, p.num_tokens, p.remove_padding = Sq, B * Sq, 0
+    if past:
+        p.sequence_lengths, p.max_kv_length = sl.data_ptr(), S
     p.act_type = L.BF16
     p.kv_type = {"bf16": L.BF16, "int8": L.INT8, "fp8": L.FP8}[kv]
     p.position_embedding_type, p.rotary_embedding_dim, p.rotary_embedding_base = 2, D, 10000.0
@@ -401,8 +408,8 @@ def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64
         rc = L.lib().mi355q_context_attention(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, L.lib().mi355q_last_error()
     _, dev_s = time_steps(step, steps, 2, lambda: None)
-    flops = 4.0 * B * H * D * (S * (S + 1) / 2)
-    return {"batch": B, "heads": H, "kv_heads": Hkv, "head_dim": D, "seq": S, "kv_cache": kv,
+    flops = 4.0 * B * H * D * (Sq * past + Sq * (Sq + 1) / 2)
+    return {"batch": B, "heads": H, "kv_heads": Hkv, "head_dim": D, "seq": S, "past_in_cache": past, "kv_cache": kv,
             "ms_per_call": dev_s / steps * 1e3, "TFLOPS_causal": flops / (dev_s / steps) / 1e12,
             "frac_of_bf16_peak": flops / (dev_s / steps) / 1e12 / 2500.0}
 
@@ -513,10 +520,10 @@ def bench_tp_row_parallel(dev, world, rank, iters=40):
     return out
 
 
-def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
-    """The oracle's C / OpenMP port of the MMHA math (oracle.c orc_decode_attention_16) on the same workload shape
-    (`seqs` of the 64 sequences x 32 heads x ctx 2048), timed on the host cores of the GPU box (one GPU's share: 16);
-    best of `reps` passes, bounded to a few tens of seconds."""
+def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, budget_s=12.0):
+    """The oracle's C / OpenMP port of the MMHA math (oracle.c orc_decode_attention_16) on the same workload (all 64
+    sequences x 32 heads x ctx 2048 = one bench step), timed on the host cores of the GPU box (one GPU's share: 16):
+    whole steps repeated for about `budget_s` seconds of wall clock; the value is the median pass."""
     import oracle
     torch.manual_seed(42)
     cores = min(16, os.cpu_count() or 1)
@@ -524,15 +531,19 @@ def cpu_baseline_attention(H=32, D=128, ctx=2048, tpb=64, seqs=64, reps=3):
     cache = oracle.PagedKVCache(seqs, H, D, ctx, tpb, torch.bfloat16)
     cache.pool.copy_((torch.randn(cache.pool.shape) * 0.5).to(torch.bfloat16))
     qkv = torch.randn(seqs, 3 * H * D).to(torch.bfloat16)
-    best = float("inf")
-    for _ in range(reps):
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 2000):
         t0 = time.perf_counter()
         oracle.decode_attention_c(qkv, cache, [ctx] * seqs, H, H, D, rope="neox")
-        best = min(best, time.perf_counter() - t0)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
     nbytes = seqs * (2 * H * ctx * D * 2 + 3 * H * D * 2 + H * D * 2 + 2 * H * D * 2)
-    return {"value": nbytes / best / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"{seqs} of 64 sequences x {H} heads x ctx {ctx}, oracle.c orc_decode_attention_16 (C, OpenMP, "
-                      f"{cores} threads), best of {reps} passes = {best:.2f} s"}
+    return {"value": nbytes / med / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"{seqs} of 64 sequences x {H} heads x ctx {ctx} (one whole step), oracle.c orc_decode_attention_16 "
+                      f"(C, OpenMP, {cores} threads): {len(times)} passes in {sum(times):.1f} s, median {med * 1e3:.1f} ms, "
+                      f"best {times[0] * 1e3:.1f} ms"}
 
 
 def main():
@@ -649,7 +660,8 @@ def main():
                 sec["rmsnorm_quant"] = [bench_rmsnorm_quant(dev, 96), bench_rmsnorm_quant(dev, 96, hidden=8192, sets=16)]
                 sec["gated_act_quant"] = bench_gated_act(dev, 48)
                 sec["context_attention"] = [bench_context_attention(dev, 10),
-                                            bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8")]
+                                            bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8"),
+                                            bench_context_attention(dev, 10, B=4, S=4096, past=2048)]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
                 sec["moe_w4_grouped_gemm"] = [bench_moe_gemm(dev, 10, tokens=64), bench_moe_gemm(dev, 10, tokens=4096)]
             except Exception as e:  # secondary numbers must never take the headline down
