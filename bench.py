@@ -265,6 +265,47 @@ def bench_moe_gemm(dev, steps, tokens=64, top_k=2, experts=8, n=28672, k=4096):
             "algorithmic_bytes": algo}
 
 
+def bench_moe_layer(dev, steps, tokens=64, top_k=2, experts=8, hidden=4096, inter=14336):
+    """§8(f) rank 4: a whole Mixtral-8x7B MoE layer with int4 weight-only experts through mi355q_run_moe: routing
+    (softmax + top-2, renormalised), sort by expert, gather, w1|w3 GEMM (4096 -> 2 x 14336), SwiGLU, w2 GEMM
+    (14336 -> 4096), finalize.  Random router logits.  Flops: the two GEMMs; bytes: the expert weights + scales (every
+    expert is hit at these token counts) + the activations in and out of each step."""
+    from mi355q import _lib as L
+    import ctypes as C
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    w1 = torch.randint(-128, 128, (experts, hidden, inter), dtype=torch.int8, device=dev)       # [E, K, 2 inter / 2]
+    w2 = torch.randint(-128, 128, (experts, inter, hidden // 2), dtype=torch.int8, device=dev)
+    s1 = (torch.rand(experts, 2 * inter, device=dev) * 0.01).to(dt)
+    s2 = (torch.rand(experts, hidden, device=dev) * 0.01).to(dt)
+    x = (torch.randn(tokens, hidden, device=dev) * 0.5).to(dt)
+    gating = torch.randn(tokens, experts, device=dev)
+    out = torch.empty(tokens, hidden, dtype=dt, device=dev)
+    p = L.MoeParams()
+    p.input, p.gating_output, p.output = x.data_ptr(), gating.data_ptr(), out.data_ptr()
+    p.fc1_expert_weights, p.fc1_scales = w1.data_ptr(), s1.data_ptr()
+    p.fc2_expert_weights, p.fc2_scales = w2.data_ptr(), s2.data_ptr()
+    p.num_rows, p.hidden_size, p.inter_size, p.num_experts, p.k = tokens, hidden, inter, experts, top_k
+    p.activation_type, p.act_type, p.weight_type, p.normalization_mode = 3, L.BF16, L.WEIGHT_INT4, 1
+    need = L.lib().mi355q_moe_workspace_size(C.byref(p))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    p.workspace, p.workspace_bytes = ws.data_ptr(), need
+
+    def step():
+        rc = L.lib().mi355q_run_moe(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, L.lib().mi355q_last_error()
+    _, dev_s = time_steps(step, steps, 2, lambda: None)
+    t = dev_s / steps
+    rows = tokens * top_k
+    flops = 2.0 * rows * hidden * 2 * inter + 2.0 * rows * inter * hidden
+    wbytes = experts * (hidden * inter + inter * hidden // 2) + experts * (2 * inter + hidden) * 2
+    abytes = tokens * hidden * 2 * 2 + rows * hidden * 2 * 4 + rows * 2 * inter * 2 * 2 + rows * inter * 2 * 2
+    return {"tokens": tokens, "top_k": top_k, "experts": experts, "hidden": hidden, "inter": inter,
+            "weights": "int4 per-column", "activation": "swiglu", "us_per_call": t * 1e6, "TFLOPS": flops / t / 1e12,
+            "GBps": (wbytes + abytes) / t / 1e9, "frac_of_8TBps": (wbytes + abytes) / t / 1e9 / HBM_PEAK_GBS,
+            "frac_of_bf16_peak": flops / t / 1e12 / (INT8_PEAK_TOPS / 2), "algorithmic_bytes": wbytes + abytes}
+
+
 def bench_prefill_w4a16(dev, steps, m=4096, n=11008, k=4096, g=128):
     """a4: prefill-M W4A16 AWQ GEMM (dequant in registers -> bf16 MFMA), Llama-2-7B gate/up shape."""
     from mi355q import _lib as L
@@ -664,6 +705,7 @@ def main():
                                             bench_context_attention(dev, 10, B=4, S=4096, past=2048)]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
                 sec["moe_w4_grouped_gemm"] = [bench_moe_gemm(dev, 10, tokens=64), bench_moe_gemm(dev, 10, tokens=4096)]
+                sec["moe_w4_layer"] = [bench_moe_layer(dev, 10, tokens=64), bench_moe_layer(dev, 10, tokens=4096)]
             except Exception as e:  # secondary numbers must never take the headline down
                 sec["error"] = repr(e)
             res["secondary"] = sec

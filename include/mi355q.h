@@ -227,8 +227,43 @@ extern "C"
         int32_t activation_type;   /* ActivationType (moe_gemm_kernels.h:27-36): 0 Gelu, 1 Relu, 2 Silu, 5 Identity */
         int32_t weight_type;       /* MI355Q_WEIGHT_INT8 / INT4 */
         int32_t act_type;          /* MI355Q_HALF / MI355Q_BF16 */
+        /* optional: fp32 scratch that lets the GEMM split K over workgroups when the rows are few (decode) and it has
+         * neither bias nor activation; splits * total_rows * gemm_n * 4 bytes are used, at most 8 splits; NULL = never */
+        void* splitk_workspace;
+        size_t splitk_workspace_bytes;
     } mi355q_moe_gemm_params;
     mi355q_status mi355q_moe_gemm_bias_act(const mi355q_moe_gemm_params* params, void* stream);
+
+    /* kernels/mixtureOfExperts/moe_kernels.h CutlassMoeFCRunner<T, uint8_t | uint4b_t>::runMoe (moe_kernels.cu:922-1035),
+     * the body of the MixtureOfExperts plugin (plugins/mixtureOfExperts/mixtureOfExpertsPlugin.cpp:388-431) for
+     * weight-only quantised experts: softmax + top-k routing, the sort of the (token, k) pairs by expert, the gather,
+     * expert GEMM 1 (+ bias, activation; Swiglu / Geglu: fc1 * act(gate) over a [.., 2 inter] GEMM), expert GEMM 2, and
+     * the un-permute / bias / routing-scale / k-way sum.  Dense (unquantised) experts are not built. */
+    typedef struct
+    {
+        const void* input;               /* act dtype [num_rows, hidden_size] */
+        const float* gating_output;      /* fp32 [num_rows, num_experts] router logits */
+        const void* fc1_expert_weights;  /* [experts_per_node] preprocessed [hidden, inter (x2 if gated)] (MI355Q_LAYOUT_GFX950) */
+        const void* fc1_scales;          /* act dtype [experts_per_node, inter (x2)] */
+        const void* fc1_expert_biases;   /* act dtype [experts_per_node, inter (x2)] or NULL */
+        const void* fc2_expert_weights;  /* [experts_per_node] preprocessed [inter, hidden] */
+        const void* fc2_scales;          /* act dtype [experts_per_node, hidden] */
+        const void* fc2_expert_biases;   /* act dtype [experts_per_node, hidden] or NULL; added on tp_rank 0 only */
+        const uint8_t* finished;         /* bool [num_rows] or NULL: finished rows are routed nowhere */
+        void* output;                    /* act dtype [num_rows, hidden_size] */
+        void* workspace;                 /* mi355q_moe_workspace_size bytes */
+        size_t workspace_bytes;
+        int32_t num_rows, hidden_size, inter_size, num_experts, k;
+        int32_t activation_type;         /* ActivationType (moe_gemm_kernels.h:27-36): 0 Gelu 1 Relu 2 Silu 3 Swiglu 4 Geglu 5 Identity */
+        int32_t act_type;                /* MI355Q_HALF / MI355Q_BF16 */
+        int32_t weight_type;             /* MI355Q_WEIGHT_INT8 / INT4 */
+        int32_t ep_size, ep_rank;        /* expert parallelism (MOEParallelismConfig): this rank owns experts
+                                            [ep_rank * num_experts / ep_size, +num_experts / ep_size); 0 / 1 = none */
+        int32_t tp_size, tp_rank;        /* tensor parallelism: inter_size is the local slice; bias 2 on rank 0 */
+        int32_t normalization_mode;      /* MOEExpertScaleNormalizationMode: 0 NONE, 1 RENORMALIZE */
+    } mi355q_moe_params;
+    size_t mi355q_moe_workspace_size(const mi355q_moe_params* params);
+    mi355q_status mi355q_run_moe(const mi355q_moe_params* params, void* stream);
 
     /* kernels/preQuantScaleKernel.cu:26-136 apply_per_channel_scale_kernel_launcher */
     mi355q_status mi355q_apply_per_channel_scale(

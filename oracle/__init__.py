@@ -252,6 +252,87 @@ def moe_gemm_bias_act(a, q_unpacked, scales, biases, total_rows_before_expert, a
     return out.to(a.dtype), out
 
 
+def moe_route(gating, k, finished=None, start_expert=0, experts_per_node=None):
+    """topkGatingSoftmax / moeSoftmax + moeTopK (kernels/mixtureOfExperts/moe_kernels.cu:62-178): fp32 softmax over the
+    experts, then k rounds of arg-max with the winner removed; equal values go to the lower index (cub::ArgMax).  Experts
+    outside [start_expert, +experts_per_node) and finished rows get the sentinel index `experts_per_node`.
+    Returns (scales fp32 [rows, k], local expert index int [rows, k])."""
+    rows, E = gating.shape
+    epn = E if experts_per_node is None else experts_per_node
+    g = gating.float()
+    p = torch.exp(g - g.max(dim=1, keepdim=True).values)
+    p = p / p.sum(dim=1, keepdim=True)
+    scales = torch.zeros(rows, k, dtype=torch.float32)
+    idx = torch.zeros(rows, k, dtype=torch.int64)
+    work = p.clone()
+    for j in range(k):
+        v, e = work.max(dim=1)  # torch.max returns the first maximal index
+        scales[:, j] = v
+        idx[:, j] = e
+        work[torch.arange(rows), e] = -1.0
+    local = idx - start_expert
+    mine = (idx >= start_expert) & (idx < start_expert + epn)
+    if finished is not None:
+        mine &= ~finished.bool().reshape(-1, 1)
+    local = torch.where(mine, local, torch.full_like(local, epn))
+    return scales, local
+
+
+def run_moe(x, gating, q1, s1, b1, q2, s2, b2, k, activation="identity", renormalize=False, finished=None,
+            ep_size=1, ep_rank=0, tp_rank=0):
+    """CutlassMoeFCRunner<T, uint8 | uint4>::runMoe (kernels/mixtureOfExperts/moe_kernels.cu:922-1035), restated:
+      * routing (moe_route); the (token, j) pairs sorted by local expert, stably in pair order token * k + j (cub radix
+        sort is stable, :499-558); total_rows_before_expert = inclusive counts (:566-578);
+      * gather of the token rows (:593-623), expert GEMM 1 with bias and activation (identity + doGatedActivation for
+        swiglu / geglu: fc1[:, :inter] * T(act(float(fc1[:, inter:]))), the product in T, :795-817), expert GEMM 2;
+      * finalize (:646-717): out = sum_j scale_j * float(T(fc2_row + bias2[expert])), the running sum held in T;
+        renormalize (k > 1): / sum_j scale_j; k == 1 with renormalize: scale 1; bias 2 only on tp rank 0 (:729-739).
+    q1: numpy int8 [E_local, hidden, inter (x2 if gated)], s1 [E_local, .], q2: [E_local, inter, hidden].
+    Returns (out in T, dict of intermediates)."""
+    T = x.dtype
+    rows, hidden = x.shape
+    E = gating.shape[1]
+    epn = E // ep_size
+    scales, local = moe_route(gating, k, finished, epn * ep_rank, epn)
+    keys = local.reshape(-1)                                  # pair i = token * k + j
+    order = torch.sort(keys, stable=True).indices             # dest -> pair
+    counts = torch.bincount(keys, minlength=epn + 1)[:epn]
+    cum = torch.cumsum(counts, 0)
+    num_valid = int(cum[-1])
+    pair_of_dest = order[:num_valid]
+    permuted = x[pair_of_dest // k]
+    gated = activation in ("swiglu", "geglu")
+    fc1, _ = moe_gemm_bias_act(permuted, q1, s1, b1, cum.tolist(), "identity" if gated else activation)
+    if gated:
+        inter = fc1.shape[1] // 2
+        g = fc1[:, inter:].float()
+        act = g * torch.sigmoid(g) if activation == "swiglu" else \
+            0.5 * g * (1.0 + torch.tanh(0.7978845608028654 * g * (1.0 + 0.044715 * g * g)))
+        fc1 = (fc1[:, :inter].float() * act.to(T).float()).to(T)
+    fc2, _ = moe_gemm_bias_act(fc1, q2, s2, None, cum.tolist(), "identity")
+    dest_of_pair = torch.empty_like(order)
+    dest_of_pair[order] = torch.arange(order.numel())
+    out = torch.zeros(rows, hidden, dtype=T)
+    rescale = torch.zeros(rows, 1)
+    mode = ("none" if k == 1 else "renorm") if renormalize else "scale"
+    for j in range(k):
+        pair = torch.arange(rows) * k + j
+        dest = dest_of_pair[pair]
+        sc = scales[:, j:j + 1] if mode != "none" else torch.ones(rows, 1)
+        rescale += sc
+        valid = dest < num_valid
+        v = torch.zeros(rows, hidden, dtype=T)
+        v[valid] = fc2[dest[valid]]
+        if b2 is not None and tp_rank == 0:
+            e = local[:, j].clamp(max=epn - 1)
+            v = torch.where(valid.reshape(-1, 1), (v + b2[e].to(T)), v)
+        term = (out.float() + sc * v.float()).to(T)
+        out = torch.where(valid.reshape(-1, 1), term, out)
+    if mode == "renorm":
+        out = (out.float() / rescale).to(T)
+    return out, dict(scales=scales, experts=local, total_rows=cum, dest_of_pair=dest_of_pair, fc2=fc2)
+
+
 def woq_tolerance(ref, wtype, dtype=None):
     """_utils.py:99-109: atol = max|ref| * 2^-(bits-1) * 1.5 (x3 for bf16 in
     cpp/tests/kernels/weightOnly/weightOnlyKernelTest.cpp:316-328)."""

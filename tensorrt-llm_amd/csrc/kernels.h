@@ -55,6 +55,8 @@ void woq_splitk_reduce(const float* slabs, const void* bias, const float* alpha,
     bool bf16, hipStream_t stream);
 void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream);
 void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream);
+size_t moe_workspace_size(const mi355q_moe_params& p);
+void run_moe(const mi355q_moe_params& p, hipStream_t stream);
 void apply_per_channel_scale(
     void* out, const void* act, const void* scale, int rows, int cols, int act_type, hipStream_t stream);
 // the W4A8 form: T(e4m3(T(act * scale))), scale may be null

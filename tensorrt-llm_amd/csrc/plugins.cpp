@@ -839,6 +839,168 @@ struct AllGatherPlugin : PluginBase
     }
 };
 
+// ===================================================================== MixtureOfExperts
+// plugins/mixtureOfExperts/mixtureOfExpertsPlugin.{h,cpp} for weight-only quantised experts (weight type INT8, int4 by
+// the quant mode): inputs hidden states, fp32 routing logits, expert weights 1 / 2, [biases 1 / 2], [finished], quant
+// scales 1 / 2 (index compaction :186-243 of the header); output = the input's shape.
+struct MixtureOfExpertsPlugin : PluginBase
+{
+    int32_t mNumExperts, mK, mHidden, mInter, mActivation, mType, mWeightType, mQuantMode;
+    bool mUseFinished, mUseBias;
+    int32_t mTPSize, mTPRank, mParallelismMode, mNormalizationMode;
+    static constexpr int32_t INT4_WEIGHTS = 1 << 0, INT8_WEIGHTS = 1 << 1; // common/quantization.h QuantMode bits
+    MixtureOfExpertsPlugin(int experts, int k, int hidden, int inter, int act, int type, int wtype, int qmode, bool finished,
+        bool bias, int tp_size, int tp_rank, int pmode, int nmode)
+        : mNumExperts(experts)
+        , mK(k)
+        , mHidden(hidden)
+        , mInter(inter)
+        , mActivation(act)
+        , mType(type)
+        , mWeightType(wtype)
+        , mQuantMode(qmode)
+        , mUseFinished(finished)
+        , mUseBias(bias)
+        , mTPSize(tp_size)
+        , mTPRank(tp_rank)
+        , mParallelismMode(pmode)
+        , mNormalizationMode(nmode)
+    {
+        // init() :156-200: (half | bf16) x INT8-typed weights with an int4 / int8 weight-only quant mode
+        if (!((mType == MI355Q_HALF || mType == MI355Q_BF16) && mWeightType == MI355Q_INT8 && hasExpertQuantScales()))
+            MQ_UNSUPPORTED("Could not construct the mixture of experts plugin with the requested input combination (built: "
+                           "half / bf16 activations with int8 / int4 weight-only experts; type %d, weight type %d, quant mode %d)",
+                mType, mWeightType, mQuantMode);
+        MQ_CHECK(mActivation >= 0 && mActivation <= 5, "activation_type %d", mActivation);
+        MQ_CHECK(mParallelismMode >= 0 && mParallelismMode <= 2, "parallelism_mode %d", mParallelismMode);
+    }
+    bool int4() const
+    {
+        return (mQuantMode & INT4_WEIGHTS) != 0;
+    }
+    bool hasExpertQuantScales() const
+    {
+        return (mQuantMode & (INT4_WEIGHTS | INT8_WEIGHTS)) != 0;
+    }
+    bool gated() const
+    {
+        return mActivation == 3 || mActivation == 4;
+    }
+    int bias1Idx() const { return 3 + mUseBias; }
+    int bias2Idx() const { return bias1Idx() + mUseBias; }
+    int finishedIdx() const { return bias2Idx() + mUseFinished; }
+    int scale1Idx() const { return finishedIdx() + 1; }
+    int scale2Idx() const { return scale1Idx() + 1; }
+    int nbInputs() const { return scale2Idx() + 1; }
+    const char* type() const override
+    {
+        return "MixtureOfExperts";
+    }
+    PluginBase* clone() const override
+    {
+        return new MixtureOfExpertsPlugin(*this);
+    }
+    void getOutputDimensions(int idx, const mi355q_dims* in, int, mi355q_dims* out) const override
+    {
+        MQ_CHECK(idx == 0, "outputIndex %d", idx);
+        *out = in[0];
+    }
+    bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int nbOut) const override // :222-254
+    {
+        MQ_CHECK(nbIn == nbInputs() && nbOut == 1 && pos >= 0 && pos < nbIn + nbOut, "MixtureOfExperts: %d inputs expected", nbInputs());
+        if (io[pos].format != 0)
+            return false;
+        if (pos == 2 || pos == 3)
+            return io[pos].type == mWeightType;
+        if (mUseFinished && pos == finishedIdx())
+            return io[pos].type == MI355Q_BOOL;
+        if (pos == 1)
+            return io[pos].type == MI355Q_FLOAT;
+        return io[pos].type == mType;
+    }
+    int getOutputDataType(int idx, const int32_t*, int) const override
+    {
+        MQ_CHECK(idx == 0, "index %d", idx);
+        return mType;
+    }
+    int numTokens(const mi355q_tensor_desc* in) const // getNumTokens :336-347
+    {
+        const int nd = in[0].dims.nbDims;
+        MQ_CHECK(nd == 2 || nd == 3, "hidden_state dimension should be either 2 [b*s, hidden], or 3 [b, s, hidden]");
+        return nd == 3 ? in[0].dims.d[0] * in[0].dims.d[1] : in[0].dims.d[0];
+    }
+    mi355q_moe_params params(int tokens) const
+    {
+        mi355q_moe_params p{};
+        p.num_rows = tokens;
+        p.hidden_size = mHidden;
+        p.inter_size = mInter;
+        p.num_experts = mNumExperts;
+        p.k = mK;
+        p.activation_type = mActivation;
+        p.act_type = mType;
+        p.weight_type = int4() ? MI355Q_WEIGHT_INT4 : MI355Q_WEIGHT_INT8;
+        p.ep_size = mParallelismMode == 1 ? mTPSize : 1; // getParallelismConfig :356-368
+        p.ep_rank = mParallelismMode == 1 ? mTPRank : 0;
+        p.tp_size = mParallelismMode == 2 ? mTPSize : 1;
+        p.tp_rank = mParallelismMode == 2 ? mTPRank : 0;
+        p.normalization_mode = mNormalizationMode;
+        return p;
+    }
+    size_t workspaceSize(const mi355q_tensor_desc* in, int, const mi355q_tensor_desc*, int) const override
+    {
+        const mi355q_moe_params p = params(numTokens(in));
+        return moe_workspace_size(p);
+    }
+    void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs, void* const* outputs,
+        void* workspace, hipStream_t stream) override // :370-431
+    {
+        mi355q_moe_params p = params(numTokens(inDesc));
+        const auto& w1 = inDesc[2].dims;
+        const auto& w2 = inDesc[3].dims;
+        const int per_node = mNumExperts / p.ep_size;
+        const int packed = int4() ? 2 : 1; // getWeightPackedElements
+        MQ_CHECK(w1.nbDims == 3 && w1.d[0] == per_node && w2.nbDims == 3 && w2.d[0] == per_node, "expert weights must be [experts, ., .]");
+        // in weight-only mode the shape is [experts, in, out (packed)] (getGemmShapeInnerDimIndex :255-259)
+        MQ_CHECK(w1.d[1] == mHidden && w1.d[2] * packed == mInter * (gated() ? 2 : 1), "expert weights 1 shape");
+        MQ_CHECK(w2.d[1] == mInter && w2.d[2] * packed == mHidden, "expert weights 2 shape");
+        p.input = inputs[0];
+        p.gating_output = static_cast<const float*>(inputs[1]);
+        p.fc1_expert_weights = inputs[2];
+        p.fc2_expert_weights = inputs[3];
+        p.fc1_expert_biases = mUseBias ? inputs[bias1Idx()] : nullptr;
+        p.fc2_expert_biases = mUseBias ? inputs[bias2Idx()] : nullptr;
+        p.finished = mUseFinished ? static_cast<const uint8_t*>(inputs[finishedIdx()]) : nullptr;
+        p.fc1_scales = inputs[scale1Idx()];
+        p.fc2_scales = inputs[scale2Idx()];
+        p.output = outputs[0];
+        p.workspace = workspace;
+        p.workspace_bytes = workspace ? moe_workspace_size(p) : 0;
+        run_moe(p, stream);
+    }
+    size_t serializationSize() const override // :88-94 without the profiler's tactics and GemmDims
+    {
+        return 8 * sizeof(int32_t) + 2 * sizeof(bool) + 4 * sizeof(int32_t);
+    }
+    void serialize(char* buf) const override
+    {
+        write(buf, mNumExperts);
+        write(buf, mK);
+        write(buf, mHidden);
+        write(buf, mInter);
+        write(buf, mActivation);
+        write(buf, mType);
+        write(buf, mWeightType);
+        write(buf, mQuantMode);
+        write(buf, mUseFinished);
+        write(buf, mUseBias);
+        write(buf, mTPSize);
+        write(buf, mTPRank);
+        write(buf, mParallelismMode);
+        write(buf, mNormalizationMode);
+    }
+};
+
 // ===================================================================== Fp8Gemm (no reference plugin)
 // inputs: 0 A e4m3 [.., K]; 1 B e4m3 [N, K]; 2 scale_a fp32 [1]; 3 scale_b fp32 [1]
 struct Fp8GemmPlugin : PluginBase
@@ -1368,7 +1530,7 @@ GptAttentionFields parse_attention_fields(const FieldReader& r) // gptAttentionP
 
 const char* const kPluginNames[] = {"WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
     "QuantizePerToken", "GPTAttention", "Fp8Gemm", "QuantizeTensor", "RmsnormQuantization", "LayernormQuantization",
-    "AllReduce", "AllGather", nullptr};
+    "AllReduce", "AllGather", "MixtureOfExperts", nullptr};
 
 PluginBase* create_plugin(const char* name, const FieldReader& r)
 {
@@ -1392,6 +1554,11 @@ PluginBase* create_plugin(const char* name, const FieldReader& r)
         return new Fp8GemmPlugin(r.req_int("type_id"));
     if (n == "QuantizeTensor")
         return new QuantizeTensorPlugin();
+    if (n == "MixtureOfExperts") // createPlugin, mixtureOfExpertsPlugin.cpp:497-556 (every field kINT32)
+        return new MixtureOfExpertsPlugin(r.req_int("number_of_experts"), r.req_int("top_k"), r.req_int("expert_hidden_size"),
+            r.req_int("expert_inter_size"), r.opt_int("activation_type", 5), r.req_int("type_id"), r.req_int("weight_type_id"),
+            r.opt_int("quant_mode", 0), r.opt_int("use_finished", 0) != 0, r.opt_int("use_bias", 0) != 0, r.opt_int("tp_size", 1),
+            r.opt_int("tp_rank", 0), r.opt_int("parallelism_mode", 0), r.opt_int("normalization_mode", 0));
     if (n == "AllGather") // createPlugin, allgatherPlugin.cpp:190-230
     {
         const mi355q_plugin_field* g = r.find("group");
@@ -1485,6 +1652,18 @@ PluginBase* deserialize_plugin(const char* name, const void* data, size_t length
     {
         need(0);
         out = new QuantizeTensorPlugin();
+    }
+    else if (n == "MixtureOfExperts") // mixtureOfExpertsPlugin.cpp:96-128
+    {
+        int32_t v[8], t[4];
+        bool fin, bias;
+        for (auto& x : v)
+            read(d, x);
+        read(d, fin);
+        read(d, bias);
+        for (auto& x : t)
+            read(d, x);
+        out = new MixtureOfExpertsPlugin(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], fin, bias, t[0], t[1], t[2], t[3]);
     }
     else if (n == "AllGather") // allgatherPlugin.cpp:36-54: type, then the group to the end
     {
@@ -1787,6 +1966,28 @@ extern "C"
             {
                 MQ_CHECK(params, "null argument");
                 moe_weight_only_gemm(*params, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    size_t mi355q_moe_workspace_size(const mi355q_moe_params* params)
+    {
+        size_t r = 0;
+        guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                r = moe_workspace_size(*params);
+            });
+        return r;
+    }
+
+    mi355q_status mi355q_run_moe(const mi355q_moe_params* params, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                MQ_CHECK(params, "null argument");
+                run_moe(*params, static_cast<hipStream_t>(stream));
             });
     }
 

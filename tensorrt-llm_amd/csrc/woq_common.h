@@ -25,6 +25,7 @@ struct WoqArgs
     const float* alpha; // device [1] or null: out = alpha * acc + bias (the W4A8 alpha, fpA_intB groupwise gemm overload)
     uint16_t* out;
     float* slabs; // [ksplit][m][n] fp32 partials when ksplit > 1
+    size_t slab_stride; // elements between two slabs in the prefill kernel (m * n; grouped GEMM: total rows * n)
     int m, n, k;
     int group;  // group size in k; == k for per-channel
     int group_shift; // log2(group); 31 for per-channel (k >> 31 == 0)

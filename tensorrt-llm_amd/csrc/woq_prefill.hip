@@ -123,6 +123,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
         a.m = rows;
         a.act += row0 * a.k;
         a.out += row0 * a.n;
+        a.slabs += row0 * a.n;
         a.qweight += (size_t) e * a.moe_wbytes;
         a.scales += (size_t) e * a.n;
         if (a.bias)
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
                         pack2<T>(woq_activation(acc[b][j][2] * alpha + bias[2], a.act_fn),
                             woq_activation(acc[b][j][3] * alpha + bias[3], a.act_fn)));
             else
-                *reinterpret_cast<float4*>(a.slabs + (size_t) blockIdx.y * a.m * a.n + oi)
+                *reinterpret_cast<float4*>(a.slabs + (size_t) blockIdx.y * a.slab_stride + oi)
                     = make_float4(acc[b][j][0], acc[b][j][1], acc[b][j][2], acc[b][j][3]);
         }
     }
@@ -438,6 +439,7 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
         "activation matrix of %d x %d exceeds the prefill kernel's 32-bit byte offsets (4 GiB)", h.m, h.k);
     a.ksplit = h.slabs ? plan_prefill(h.m, h.n, h.k, h.int4 ? 4 : 8).ksplit : 1;
     a.slabs = h.slabs;
+    a.slab_stride = (size_t) h.m * h.n;
     const bool bf = h.bf16, i4 = h.int4, z = h.zeros != nullptr;
     if (bf && i4 && z) launch_prefill<bf16_t, 4, true>(a, stream);
     else if (bf && i4) launch_prefill<bf16_t, 4, false>(a, stream);
@@ -488,6 +490,26 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     a.ktiles = a.k / (i4 ? 128 : 64);
     a.ksplit = 1;
     a.act_fn = p.activation_type;
+    // split K over grid.y while the tiles leave most CUs idle (decode: the w2 GEMM has few n-tiles and a long k):
+    // fp32 slabs in the caller's workspace + the reduce launch; only without bias / activation (moeGemm), whose
+    // epilogue the reduce kernel then is
+    {
+        const int ktiles = (int) (p.gemm_k / (i4 ? 128 : 64));
+        const int64_t wgs = (p.gemm_n / 128) * ((p.total_rows + 31) / 32 + p.num_experts);
+        int ks = 1;
+        if (p.splitk_workspace && !p.biases && p.activation_type == 5 && wgs < 768 && ktiles >= 16)
+        {
+            ks = (int) std::min<int64_t>(std::min<int64_t>(8, ktiles / 8), (2048 + wgs - 1) / wgs);
+            const size_t per = (size_t) p.total_rows * p.gemm_n * sizeof(float);
+            ks = (int) std::min<size_t>(ks, p.splitk_workspace_bytes / per);
+        }
+        if (ks > 1)
+        {
+            a.ksplit = ks;
+            a.slabs = static_cast<float*>(p.splitk_workspace);
+            a.slab_stride = (size_t) p.total_rows * p.gemm_n;
+        }
+    }
     a.moe_rows = p.total_rows_before_expert;
     a.moe_experts = p.num_experts;
     a.moe_wbytes = (size_t) p.gemm_n * p.gemm_k * (i4 ? 1 : 2) / 2;
@@ -498,7 +520,7 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     const int tiles_n = a.n / 128;
     const bool bf = p.act_type == MI355Q_BF16;
 #define MQ_MOE(T, WB, MTV)                                                                                             \
-    hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2>), dim3(tiles_m * tiles_n, 1), dim3(PF_WAVES * 64), 0,  \
+    hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2>), dim3(tiles_m * tiles_n, a.ksplit), dim3(PF_WAVES * 64), 0,  \
         stream, a, tiles_m, tiles_n)
 #define MQ_MOE_MT(T, WB)                                                                                               \
     do                                                                                                                 \
@@ -516,6 +538,8 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     else MQ_MOE_MT(f16_t, 8);
 #undef MQ_MOE_MT
 #undef MQ_MOE
+    if (a.ksplit > 1) // rows past the last expert's hold whatever the workspace held: nobody reads them
+        woq_splitk_reduce(a.slabs, nullptr, nullptr, p.C, (int) p.total_rows, (int) p.gemm_n, a.ksplit, bf, stream);
     MQ_HIP(hipGetLastError());
 }
 

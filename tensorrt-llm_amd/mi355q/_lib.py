@@ -70,6 +70,20 @@ class MoeGemmParams(C.Structure):
         ("total_rows_before_expert", C.c_void_p),
         ("total_rows", C.c_int64), ("gemm_n", C.c_int64), ("gemm_k", C.c_int64),
         ("num_experts", C.c_int32), ("activation_type", C.c_int32), ("weight_type", C.c_int32), ("act_type", C.c_int32),
+        ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_size_t),
+    ]
+
+
+class MoeParams(C.Structure):
+    _fields_ = [
+        ("input", C.c_void_p), ("gating_output", C.c_void_p),
+        ("fc1_expert_weights", C.c_void_p), ("fc1_scales", C.c_void_p), ("fc1_expert_biases", C.c_void_p),
+        ("fc2_expert_weights", C.c_void_p), ("fc2_scales", C.c_void_p), ("fc2_expert_biases", C.c_void_p),
+        ("finished", C.c_void_p), ("output", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("num_rows", C.c_int32), ("hidden_size", C.c_int32), ("inter_size", C.c_int32), ("num_experts", C.c_int32),
+        ("k", C.c_int32), ("activation_type", C.c_int32), ("act_type", C.c_int32), ("weight_type", C.c_int32),
+        ("ep_size", C.c_int32), ("ep_rank", C.c_int32), ("tp_size", C.c_int32), ("tp_rank", C.c_int32),
+        ("normalization_mode", C.c_int32),
     ]
 
 
@@ -187,6 +201,8 @@ SYMBOLS = {
     "mi355q_fp8_gemm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_quantize_e4m3": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_moe_gemm_bias_act": (_i32, [C.POINTER(MoeGemmParams), _vp]),
+    "mi355q_moe_workspace_size": (_sz, [C.POINTER(MoeParams)]),
+    "mi355q_run_moe": (_i32, [C.POINTER(MoeParams), _vp]),
     "mi355q_decode_attention_workspace_size": (_sz, [C.POINTER(DecodeAttentionParams)]),
     "mi355q_masked_multihead_attention": (_i32, [C.POINTER(DecodeAttentionParams), _vp]),
     "mi355q_decode_attention_static_scratch_size": (_sz, []),

@@ -152,6 +152,36 @@ def moe_gemm_bias_act(a, expert_weights, weight_scales, biases, total_rows_befor
     return out
 
 
+def mixture_of_experts(hidden_states, routing, expert_weights_1, expert_weights_2, expert_scales_1, expert_scales_2,
+                       top_k, activation_type, weight_type_id, expert_bias_1=None, expert_bias_2=None, finished=None,
+                       normalization_mode=0, tp_size=1, tp_rank=0, parallelism_mode=0):
+    """tensorrt_llm/layers/moe.py `_moe_plugin`: the MixtureOfExperts plugin with weight-only quantised experts.
+    expert_weights_*: int8 [E_local, in, out] (int8) or [E_local, in, out / 2] (packed int4) already preprocessed per
+    expert; routing: fp32 [tokens, E] logits.  Returns the hidden states' shape."""
+    hidden = hidden_states.shape[-1]
+    int4 = weight_type_id == L.WEIGHT_INT4
+    E = routing.shape[-1]
+    gated = activation_type in (ACT_SWIGLU, ACT_GEGLU)
+    inter = expert_weights_1.shape[2] * (2 if int4 else 1) // (2 if gated else 1)
+    fields = [("number_of_experts", E, L.FIELD_INT32), ("top_k", top_k, L.FIELD_INT32),
+              ("expert_hidden_size", hidden, L.FIELD_INT32), ("expert_inter_size", inter, L.FIELD_INT32),
+              ("activation_type", activation_type, L.FIELD_INT32),
+              ("type_id", L.HALF if hidden_states.dtype == torch.float16 else L.BF16, L.FIELD_INT32),
+              ("weight_type_id", L.INT8, L.FIELD_INT32), ("quant_mode", 1 if int4 else 2, L.FIELD_INT32),
+              ("use_finished", int(finished is not None), L.FIELD_INT32),
+              ("use_bias", int(expert_bias_1 is not None), L.FIELD_INT32),
+              ("tp_size", tp_size, L.FIELD_INT32), ("tp_rank", tp_rank, L.FIELD_INT32),
+              ("parallelism_mode", parallelism_mode, L.FIELD_INT32),
+              ("normalization_mode", normalization_mode, L.FIELD_INT32)]
+    inputs = [hidden_states, routing, expert_weights_1, expert_weights_2]
+    if expert_bias_1 is not None:
+        inputs += [expert_bias_1, expert_bias_2]
+    if finished is not None:
+        inputs += [finished]
+    inputs += [expert_scales_1, expert_scales_2]
+    return Plugin("MixtureOfExperts", fields)(*inputs)
+
+
 def weight_only_quant_matmul(input, weights, scales, weightTypeId, dtype="float16"):
     """quantization/functional.py:68-104.  weights: int8 [K, N] (int8) or [K, N/2] (packed int4)."""
     plg = Plugin("WeightOnlyQuantMatmul", [

@@ -32,7 +32,8 @@ def test_version_and_plugin_names():
     assert b"gfx950" in L.lib().mi355q_version()
     assert get_plugin_names() == ["WeightOnlyGroupwiseQuantMatmul", "WeightOnlyQuantMatmul", "SmoothQuantGemm",
                                   "QuantizePerToken", "GPTAttention", "Fp8Gemm", "QuantizeTensor",
-                                  "RmsnormQuantization", "LayernormQuantization", "AllReduce", "AllGather"]
+                                  "RmsnormQuantization", "LayernormQuantization", "AllReduce", "AllGather",
+                                  "MixtureOfExperts"]
 
 
 @pytest.mark.parametrize("qt,tq", [(oracle.INT8_W, torch.int8), (oracle.INT4_W, torch.quint4x2)])
