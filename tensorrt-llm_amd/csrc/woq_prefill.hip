@@ -73,8 +73,17 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
     return p;
 }
 
+template <int I>
+struct PfSlot
+{
+    static constexpr int value = I;
+};
+
 // grid.x = tiles_m * tiles_n (remapped XCD-contiguous, m fastest: neighbours share the weight panel)
-template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB>
+// DEPTH: tiles of the k loop in flight + 1.  2 = ping-pong (one tile ahead: enough when a tile's MFMAs outlast a load);
+// 4 = a ring with three tiles ahead for the short tiles (MT <= 4, i.e. m <= 64 per workgroup: a tile is 16-32 MFMAs per
+// wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2>
 __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
 {
     constexpr int PF_TN = NB * 16 * PF_WAVES;
@@ -87,7 +96,8 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     constexpr int BUF_BYTES = TM * RB;
     constexpr int DMA_PER_TILE = BUF_BYTES / 1024;
     constexpr int DMA_PER_WAVE = (DMA_PER_TILE + PF_WAVES - 1) / PF_WAVES;
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF_BYTES];
+    static_assert(DEPTH == 2 || DMA_PER_TILE % PF_WAVES == 0, "the ring counts its loads: every wave must issue the same number");
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[DEPTH * BUF_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -248,15 +258,18 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
 
     // full tiles [kt_lo, nfull) run in the ping-pong loop; the int4 half tile (if it falls into this split) afterwards
     const int nfull = min(nk, a.ktiles);
-    WTile wt[2];
-    if (kt_lo < nfull)
+    WTile wt[DEPTH];
+    if constexpr (DEPTH == 2)
     {
-        stage(kt_lo, 0);
-        load_w(wt[0], kt_lo);
+        if (kt_lo < nfull)
+        {
+            stage(kt_lo, 0);
+            load_w(wt[0], kt_lo);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(wt[0]);
+        __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed(wt[0]);
-    __syncthreads();
 
     auto compute = [&](const WTile& t, int buf, int steps)
     {
@@ -310,24 +323,76 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
         landed(next);
         __syncthreads();
     };
-    for (int kt = kt_lo; kt < nfull; kt += 2)
+    if constexpr (DEPTH == 2)
     {
-        if (kt + 1 < nfull)
+        for (int kt = kt_lo; kt < nfull; kt += 2)
         {
-            stage(kt + 1, 1);
-            load_w(wt[1], kt + 1);
+            if (kt + 1 < nfull)
+            {
+                stage(kt + 1, 1);
+                load_w(wt[1], kt + 1);
+            }
+            compute(wt[0], 0, KSTEPS);
+            boundary(wt[1]);
+            if (kt + 1 >= nfull)
+                break;
+            if (kt + 2 < nfull)
+            {
+                stage(kt + 2, 0);
+                load_w(wt[0], kt + 2);
+            }
+            compute(wt[1], 1, KSTEPS);
+            boundary(wt[0]);
         }
-        compute(wt[0], 0, KSTEPS);
-        boundary(wt[1]);
-        if (kt + 1 >= nfull)
-            break;
-        if (kt + 2 < nfull)
+    }
+    else
+    {
+        // the ring.  Vector-memory operations a wave issues per tile, in issue order: DMA_PER_WAVE LDS-DMAs, then the
+        // weight and scale / zero loads.  vmcnt retires in order, so "tile kt has landed" = at most (tiles issued
+        // after it) x L operations outstanding.  hipcc cannot see the DMAs and adds its own, somewhat stricter wait
+        // in front of landed(); the explicit one is what covers the DMAs.
+        constexpr int L = DMA_PER_WAVE + NB * (1 + NSZ * (ZERO ? 2 : 1));
+        static_assert((DEPTH - 2) * L < 64, "vmcnt immediate");
+        auto issue = [&](auto slot, int kt)
         {
-            stage(kt + 2, 0);
-            load_w(wt[0], kt + 2);
+            constexpr int s = decltype(slot)::value;
+            stage(kt, s);
+            load_w(wt[s], kt);
+        };
+        auto step = [&](auto slot, int kt)
+        {
+            constexpr int s = decltype(slot)::value;
+            const int later = min(DEPTH - 2, nfull - 1 - kt); // tiles issued after tile kt
+            if (later >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+            else if (later == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed(wt[s]);
+            __syncthreads(); // every wave's share of tile kt is in LDS; every wave is done with tile kt - 1's buffer
+            if (kt + DEPTH - 1 < nfull)
+                issue(PfSlot<(s + DEPTH - 1) % DEPTH>{}, kt + DEPTH - 1);
+            compute(wt[s], s, KSTEPS);
+        };
+        static_assert(DEPTH == 4, "the ring is written out for 4 slots");
+        if (kt_lo < nfull)
+            issue(PfSlot<0>{}, kt_lo);
+        if (kt_lo + 1 < nfull)
+            issue(PfSlot<1>{}, kt_lo + 1);
+        if (kt_lo + 2 < nfull)
+            issue(PfSlot<2>{}, kt_lo + 2);
+        for (int kt = kt_lo; kt < nfull; kt += 4)
+        {
+            step(PfSlot<0>{}, kt);
+            if (kt + 1 < nfull)
+                step(PfSlot<1>{}, kt + 1);
+            if (kt + 2 < nfull)
+                step(PfSlot<2>{}, kt + 2);
+            if (kt + 3 < nfull)
+                step(PfSlot<3>{}, kt + 3);
         }
-        compute(wt[1], 1, KSTEPS);
-        boundary(wt[0]);
+        __syncthreads(); // the half tile below restages buffer 0
     }
     if (WBITS == 4 && nk > nfull) // the half tile: both buffers are free after the last boundary
     {
@@ -377,6 +442,8 @@ template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB>
 void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
 {
     const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 64);
+    // (the 4-slot ring of the grouped MoE launch was measured here too, m = 40 - 64 at seven Llama shapes: 2 - 17 %
+    // SLOWER than the ping-pong -- these launches are split over K into 4-tile pieces, a ring never fills)
     hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB>), dim3(tiles_m * tiles_n, a.ksplit),
         dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);
 }
@@ -520,8 +587,15 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     const int tiles_n = a.n / 128;
     const bool bf = p.act_type == MI355Q_BF16;
 #define MQ_MOE(T, WB, MTV)                                                                                             \
-    hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2>), dim3(tiles_m * tiles_n, a.ksplit), dim3(PF_WAVES * 64), 0,  \
-        stream, a, tiles_m, tiles_n)
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (MTV <= 4 && !lab_env("MI355Q_PF_DEPTH2"))                                                                  \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 4 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \
+                dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);                                                  \
+        else                                                                                                           \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2>), dim3(tiles_m * tiles_n, a.ksplit),       \
+                dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);                                                  \
+    } while (0)
 #define MQ_MOE_MT(T, WB)                                                                                               \
     do                                                                                                                 \
     {                                                                                                                  \
