@@ -412,7 +412,7 @@ constexpr int CTX_QW = 32;   // query rows per wave
 // CACHED: K / V of keys 0 .. kv_len - 1 come from the (16-bit) cache, the query rows sit at positions past .. (chunked
 // context); else from the workspace rows of this call (past = 0).  BIAS: ALiBi, scores biased before the softmax.
 template <typename T, int DH, int NWV, bool CACHED, bool BIAS>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void ctx_attn_kernel(CtxArgs p)
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 128 ? 1 : 2))) void ctx_attn_kernel(CtxArgs p)
 {
     constexpr int CTX_QB = CTX_QW * NWV;    // query rows per workgroup: 128 (4 waves, short sequences) / 256 (8 waves)
     constexpr int KS = DH / 32;             // QK k-steps
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
 
     // swizzles of the 16-byte chunk index by tile row.  K: 16 consecutive rows x one logical chunk (a ds_read_b128
     // fragment) cover all 64 banks once.  V: the transposing 8-byte reads of 4 row groups do.
-    auto ksw = [](int row) { return CH == 16 ? (row & 15) : ((row >> 1) & 7); };
+    auto ksw = [](int row) { return CH >= 16 ? (row & 15) : ((row >> 1) & 7); };
     auto vsw = [](int row) { return (((row & 3) << 2) | ((row >> 2) & 3)) & (CH - 1); };
 
     // ---- DMA staging: instruction d of a tile fills LDS bytes [1024 d, +1024): lane -> (row, stored chunk)
@@ -747,7 +747,8 @@ int ctx_ilog2(int x)
 
 size_t context_attention_workspace_size(const mi355q_context_attention_params& q)
 {
-    const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * (q.head_size <= 64 ? 64 : 128); // padded rows
+    const size_t hidden
+        = (size_t) (q.num_heads + 2 * q.num_kv_heads) * (q.head_size <= 64 ? 64 : (q.head_size <= 128 ? 128 : 256)); // padded rows
     const size_t tokens = q.remove_padding ? (size_t) q.num_tokens : (size_t) q.batch * q.max_context_length;
     return tokens * hidden * 2 + ((size_t) q.batch * sizeof(int32_t) + 255) / 256 * 256;
 }
@@ -759,9 +760,10 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     MQ_CHECK(q.batch >= 0 && q.num_heads > 0 && q.num_kv_heads > 0 && q.num_heads % q.num_kv_heads == 0, "bad sizes");
     // 64 / 128 run as they are; other multiples of 8 up to 128 are zero-padded to the next of the two in the workspace
     // (the reference's context FMHA is built for 32, 40, 64, 80, 128, 160, 256; its unfused path takes any size)
-    MQ_CHECK(q.head_size >= 8 && q.head_size <= 128 && q.head_size % 8 == 0,
-        "context attention: head_size %d not built (multiples of 8 up to 128)", q.head_size);
-    const int dh_pad = q.head_size <= 64 ? 64 : 128;
+    // (256: one workgroup per CU -- 128 KiB of K / V stages and ~300 registers per lane -- a functional path, not a tuned one)
+    MQ_CHECK(q.head_size >= 8 && q.head_size <= 256 && q.head_size % 8 == 0,
+        "context attention: head_size %d not built (multiples of 8 up to 256)", q.head_size);
+    const int dh_pad = q.head_size <= 64 ? 64 : (q.head_size <= 128 ? 128 : 256);
     if (q.batch == 0 || q.max_context_length == 0)
         return;
     const size_t need = context_attention_workspace_size(q);
@@ -875,7 +877,7 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     const dim3 pgrid(q.max_context_length, q.batch);
     const size_t plds = (hidden + q.head_size) * sizeof(float);
     MQ_CHECK(plds <= 64 * 1024, "qkv hidden size %zu too large for the prepare kernel", hidden);
-    const bool fast = dh_pad == q.head_size
+    const bool fast = dh_pad == q.head_size && q.head_size <= 128 // (the fast kernel's cos / sin table holds 64 pairs)
         && (q.position_embedding_type == 0 || q.position_embedding_type == 1 || q.position_embedding_type == 3
             || q.position_embedding_type == 4 || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size));
     if (fast && bf)
@@ -903,7 +905,11 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
         else                                                                                                           \
             MQ_CTX_LAUNCH2(TT, DD, false, false);                                                                      \
     } while (0)
-    if (bf && dh_pad == 128)
+    if (bf && dh_pad == 256)
+        MQ_CTX_LAUNCH(bf16_t, 256);
+    else if (dh_pad == 256)
+        MQ_CTX_LAUNCH(f16_t, 256);
+    else if (bf && dh_pad == 128)
         MQ_CTX_LAUNCH(bf16_t, 128);
     else if (bf)
         MQ_CTX_LAUNCH(bf16_t, 64);

@@ -174,7 +174,7 @@ def test_context_large_logits(cuda):
                 assert (o.float() - r.float()).abs().max().item() <= ATOL[dtype] * 8  # outputs of magnitude ~8
 
 
-@pytest.mark.parametrize("D", [32, 48, 80, 96, 112])
+@pytest.mark.parametrize("D", [32, 48, 80, 96, 112, 160, 192, 256])
 def test_context_other_head_sizes(cuda, D):
     # head sizes besides 64 / 128: zero-padded to the next of the two in the workspace (the cache and the output keep the
     # real size); RoPE (generic prepare kernel), bias, 16-bit and 8-bit caches
@@ -293,7 +293,7 @@ def test_context_c_abi_without_cache_and_errors(cuda):
     assert L.lib().mi355q_context_attention(C.byref(p), None) != 0
     assert b"workspace" in L.lib().mi355q_last_error()
     p.workspace_bytes = need
-    p.head_size = 160
+    p.head_size = 260
     assert L.lib().mi355q_context_attention(C.byref(p), None) != 0
 
 
