@@ -829,6 +829,188 @@ __global__ __launch_bounds__(256) void gemm8_w128_kernel(Gemm8Args g, int tiles_
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// LAB BUILD ONLY -- experiment: the phased kernel is co-bound by the LDS port (fragment reads + LDS-DMA writes of BOTH
+// operands = 2048 port cycles per K-tile against 2048 MFMA cycles per SIMD).  Here only the ACTIVATIONS go
+// through the LDS; every wave loads its WEIGHT fragments (the MFMA A operand: 16 rows x 64 bytes per instruction)
+// straight from global memory / L2 into registers, one K-tile ahead, and an extra one-dword touch per weight row pulls
+// the K-tile after next into the L2.  256 x 256 tile, 8 waves = 2 (m) x 4 (n), wave tile 128 x 64, K-tile 128 bytes.
+//   LDS: 3 K-tiles of the 256 activation rows (32 KiB each, rows XOR-swizzled as in the phased kernel), filled by
+//        LDS-DMA two tiles ahead, 4 instructions per wave and tile; one s_barrier per K-tile.
+//   Per iteration a wave issues, in this order: 8 weight loads (tile t+1), 4 DMAs (tile t+2), 1 L2 touch (tile t+3);
+//   vmcnt retires in order, so "s_waitcnt vmcnt(5)" at the top of the next iteration = weights of t+1 (and, older, the
+//   DMAs of t+1) have landed, the DMAs of t+2 and the touch stay in flight.
+//   The weight loads are asm statements (invisible to hipcc's own vmcnt bookkeeping, which would otherwise wait for
+//   newer loads as well); `landed` re-defines the registers after the explicit wait.
+// abl: bit 0 = no L2 touch; bit 1 = the weight loads always hit tile 0 (measures the loads' issue cost without misses).
+__global__ __launch_bounds__(512) void gemm8_direct_kernel(Gemm8Args g, int tiles_m, int tiles_n, int group_m, int abl)
+{
+    constexpr int TK = 128, NBUF = 3;
+    constexpr int ABYTES = 256 * TK; // 32 KiB
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[NBUF * ABYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int per_group = group_m * tiles_n;
+    const int first_tm = (bid / per_group) * group_m;
+    const int gsz = min(group_m, tiles_m - first_tm);
+    const int tm = first_tm + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+    const size_t m0 = (size_t) tm * 256, n0 = (size_t) tn * 256;
+    const int nk = g.k / TK;
+
+    // activations: DMA d = wave * 4 + i covers tile rows [8d, 8d + 8); stored chunk c' of row u = source chunk c' ^ ((u >> 1) & 7)
+    const uint8_t* asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const int u = (wave * 4 + i) * 8 + (lane >> 3);
+        asrc[i] = g.A + (m0 + u) * g.k + (((lane & 7) ^ ((u >> 1) & 7)) << 4);
+    }
+    auto stage_a = [&](int kt)
+    {
+        const int t = min(kt, nk - 1);
+        uint8_t* dst = lds + (kt % NBUF) * ABYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*) (asrc[i] + (size_t) t * TK), (lds_void_t*) (dst + i * 1024), 16, 0, 0);
+    };
+    // weights: lane -> row (l & 15) of n-tile j, bytes [(l >> 4) * 16, +16) of k-step ks
+    const uint8_t* wsrc = g.B + (n0 + wc * 64 + (lane & 15)) * g.k + (lane >> 4) * 16;
+    const size_t wj = (size_t) 16 * g.k;
+    auto load_w = [&](i32x4_t (&fb)[4][2], int kt)
+    {
+        // abl bit 1: every tile re-reads tile 0's weights (same instruction count, always L2 / TCP hits; wrong results)
+        const uint8_t* p = wsrc + ((abl & 2) ? 0 : (size_t) min(kt, nk - 1) * TK);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[j][0]) : "v"(p + j * wj));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(fb[j][1]) : "v"(p + j * wj));
+        }
+    };
+    auto landed = [&](i32x4_t (&fb)[4][2])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("" : "+v"(fb[j][0]), "+v"(fb[j][1]));
+    };
+    const uint8_t* tsrc = g.B + (n0 + (tid & 255)) * g.k; // one dword of every weight row of the tile after next: an L2 touch
+    int junk0 = 0, junk1 = 0;
+    auto touch = [&](int& junk, int kt)
+    {
+        asm volatile("" ::"v"(junk)); // the touch issued into this register two iterations ago has retired (in order)
+        if (!(abl & 1))
+            asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(tsrc + (size_t) min(kt, nk - 1) * TK));
+        else
+            asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(tsrc)); // same op count, a line already in the L2
+    };
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int fsw = (frow >> 1) & 7;
+    const int off_k0 = frow * TK + ((fk ^ fsw) << 4), off_k1 = frow * TK + (((4 + fk) ^ fsw) << 4);
+    const int a_row0 = wr * 128 * TK;
+
+    i32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = i32x4_t{0, 0, 0, 0};
+    i32x4_t fbx[4][2], fby[4][2], fa[4][2];
+
+    auto half = [&](const uint8_t* buf, int h, const i32x4_t (&fb)[4][2])
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            fa[i][0] = *reinterpret_cast<const i32x4_t*>(buf + a_row0 + (h * 4 + i) * 16 * TK + off_k0);
+            fa[i][1] = *reinterpret_cast<const i32x4_t*>(buf + a_row0 + (h * 4 + i) * 16 * TK + off_k1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[h * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[j][ks], fa[i][ks], acc[h * 4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto iteration = [&](int kt, i32x4_t (&cur)[4][2], i32x4_t (&nxt)[4][2], int& junk)
+    {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); // weights of tile kt (and this wave's DMAs of tile kt) have landed
+        landed(cur);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wave's DMAs of tile kt have landed; every wave is done with tile kt - 1
+        asm volatile("" ::: "memory");
+        load_w(nxt, kt + 1);
+        stage_a(kt + 2);
+        touch(junk, kt + 3);
+        const uint8_t* buf = lds + (kt % NBUF) * ABYTES;
+        half(buf, 0, cur);
+        half(buf, 1, cur);
+    };
+
+    // prologue, in the steady state's order: [A 0] [W 0] [A 1] [touch]
+    stage_a(0);
+    load_w(fbx, 0);
+    stage_a(1);
+    touch(junk1, 2);
+    for (int kt = 0; kt < nk; kt += 2)
+    {
+        iteration(kt, fbx, fby, junk0);
+        if (kt + 1 < nk)
+            iteration(kt + 1, fby, fbx, junk1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the clamped tail loads write registers / LDS: let them land
+    landed(fbx);
+    landed(fby);
+    asm volatile("" ::"v"(junk0), "v"(junk1));
+
+    const int em = lane & 15, en = (lane >> 4) * 4;
+    float sr[8], sc[4][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        sr[i] = g.alpha_row[g.per_token ? m0 + wr * 128 + i * 16 + em : 0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        gemm8_col_scales(g, n0 + wc * 64 + j * 16 + en, sc[j]);
+    gemm8_dispatch_out(g.out_type, [&](auto out)
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const size_t row = m0 + wr * 128 + i * 16 + em;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const size_t col = n0 + wc * 64 + j * 16 + en;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (float) acc[i][j][r] * (sc[j][r] * sr[i]);
+                gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
+            }
+        }
+    });
+}
+
+void launch_direct(const Gemm8Args& g, hipStream_t stream)
+{
+    static const int group_m = lab_env("MI355Q_GEMM8_GROUP_M") ? std::max(1, atoi(lab_env("MI355Q_GEMM8_GROUP_M"))) : 4;
+    const int abl = lab_env("MI355Q_GEMM8_ABL") ? atoi(lab_env("MI355Q_GEMM8_ABL")) : 0;
+    hipLaunchKernelGGL(gemm8_direct_kernel, dim3((g.m / 256) * (g.n / 256)), dim3(512), 0, stream, g, g.m / 256, g.n / 256,
+        group_m, abl);
+}
+
 void launch_w128(const Gemm8Args& g, hipStream_t stream)
 {
     static const int group_m = lab_env("MI355Q_GEMM8_GROUP_M") ? std::max(1, atoi(lab_env("MI355Q_GEMM8_GROUP_M"))) : 4;
@@ -885,6 +1067,11 @@ void launch_tile(int c, const Gemm8Args& g, hipStream_t stream)
         if (lab_env("MI355Q_GEMM8_W128")) // lab: the 4-wave 128 x 128 wave-tile experiment (read per call: A/B in one process)
         {
             launch_w128(g, stream);
+            break;
+        }
+        if (lab_env("MI355Q_GEMM8_DIRECT") && g.k / 128 >= 3) // lab: weights straight from L2 into the fragments
+        {
+            launch_direct(g, stream);
             break;
         }
 #endif
