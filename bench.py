@@ -549,6 +549,24 @@ def bench_tp_row_parallel(dev, world, rank, iters=40):
                     line["custom_allreduce_us"], line["custom_bus_GBps"] = t, bus(t)
                     line["custom_strategy"] = {1: "oneshot", 2: "twoshot", 0: "ring"}[
                         L.lib().mi355q_allreduce_select_implementation(nbytes, world, helper.size)]
+                    # the AllGather plugin's kernel on the same buffers (gather_output of a column-parallel layer):
+                    # every rank's [m, n] block back to back; checked against RCCL's all-gather
+                    gath = torch.empty(world * m, n, dtype=dt, device=dev)
+                    gbus = lambda us: (world - 1) * nbytes / (us * 1e-6) / 1e9
+
+                    def custom_gather():
+                        helper.allgather(y, out=gath, direct=True)
+                    t = timed(custom_gather)
+                    line["custom_allgather_us"], line["custom_allgather_bus_GBps"] = t, gbus(t)
+                    if dist.get_backend() == "nccl":
+                        ref = torch.empty_like(gath)
+
+                        def rccl_gather():
+                            dist.all_gather_into_tensor(ref, y)
+                        t = timed(rccl_gather)
+                        line["rccl_allgather_us"], line["rccl_allgather_bus_GBps"] = t, gbus(t)
+                        torch.cuda.synchronize()
+                        line["allgather_matches_rccl"] = bool(torch.equal(ref, gath))
                     ok = not helper.timed_out()
                 except Exception as e:  # noqa: BLE001
                     ok, line["custom_error"] = False, repr(e)
