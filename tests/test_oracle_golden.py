@@ -276,3 +276,69 @@ def test_w4a8_awq_oracle_known_answers():
     out16, out32 = oracle.woq_groupwise_matmul(act, None, q, scale, None, bias, 64, alpha=torch.tensor([0.5]), act_fp8=True)
     assert out32[0, 0].item() == (1.0 + 1.25 + 448.0 - 6.0) * 0.5 + 0.5
     assert out32[0, 1].item() == 0.5
+
+
+def test_moe_route_ties_and_known_answers():
+    # moeTopK (moe_kernels.cu:120-178): arg-max with the lower index winning ties (cub::ArgMax); scales are the softmax
+    # probabilities of the chosen experts; experts of other ranks / finished rows get the sentinel
+    g = torch.tensor([[0.25, 0.25, 0.25, 0.25], [1.0, 3.0, 3.0, 0.0], [0.0, 0.0, 5.0, 1.0]])
+    s, e = oracle.moe_route(g, 2)
+    assert e.tolist() == [[0, 1], [1, 2], [2, 3]]
+    p = torch.softmax(g, dim=1)
+    assert torch.allclose(s[0], p[0, :2]) and torch.allclose(s[2], torch.stack([p[2, 2], p[2, 3]]))
+    # expert parallelism, rank 1 of 2: experts 2, 3 are local (0, 1), the others the sentinel 2; finished row 0
+    s2, e2 = oracle.moe_route(g, 2, finished=torch.tensor([True, False, False]), start_expert=2, experts_per_node=2)
+    assert e2.tolist() == [[2, 2], [2, 0], [0, 1]] and torch.equal(s, s2)
+
+
+def test_run_moe_properties():
+    # (i) identical experts + renormalised scales: the layer equals ONE expert's FFN whatever the routing says
+    # (ii) top-1 with renormalisation: scale 1 (finalizeMoeRoutingKernelLauncherSelectBias, moe_kernels.cu:735-739)
+    torch.manual_seed(0)
+    E, h, inter, rows = 4, 32, 64, 24
+    rng = np.random.default_rng(0)
+    q1 = np.repeat(rng.integers(-127, 128, (1, h, inter), dtype=np.int8), E, 0)
+    q2 = np.repeat(rng.integers(-127, 128, (1, inter, h), dtype=np.int8), E, 0)
+    s1 = (torch.rand(1, inter) * 0.02).half().repeat(E, 1)
+    s2 = (torch.rand(1, h) * 0.02).half().repeat(E, 1)
+    x = (torch.randn(rows, h) * 0.5).half()
+    gate = torch.randn(rows, E)
+    one, _ = oracle.run_moe(x, torch.zeros(rows, 1), q1[:1], s1[:1], None, q2[:1], s2[:1], None, 1, "relu", True)
+    for k in (1, 2, 4):
+        out, mid = oracle.run_moe(x, gate, q1, s1, None, q2, s2, None, k, "relu", True)
+        tol = 4 * 2.0 ** -10 * max(one.float().abs().max().item(), 1.0)  # the k-way sum is held in fp16
+        assert (out.float() - one.float()).abs().max().item() <= tol
+        assert int(mid["total_rows"][-1]) == rows * k
+    # (iii) the sort is stable: within an expert the rows keep pair order token * k + j
+    out, mid = oracle.run_moe(x, gate, q1, s1, None, q2, s2, None, 2, "relu", False)
+    dest = mid["dest_of_pair"]
+    keys = mid["experts"].reshape(-1)
+    for e in range(E):
+        d = dest[keys == e]
+        assert torch.equal(d, torch.sort(d).values)
+
+
+def test_context_attention_oracle_chunks_window_alibi():
+    # chunked context == one shot; a window at least as long as the context == none; zero ALiBi slopes == none;
+    # a sliding window really drops keys
+    torch.manual_seed(1)
+    Hq, Hkv, D, S = 4, 2, 32, 50
+    rows = [(torch.randn(S, (Hq + 2 * Hkv) * D) * 0.5).half()]
+    whole = oracle.context_attention(rows, [S], Hq, Hkv, D, rope="neox", rot_dim=D)[0]
+    cache = oracle.PagedKVCache(1, Hkv, D, 64, 16, torch.float16)
+    a = oracle.context_attention([rows[0][:20]], [20], Hq, Hkv, D, cache=cache, rope="neox", rot_dim=D)[0]
+    b = oracle.context_attention([rows[0][20:]], [30], Hq, Hkv, D, cache=cache, rope="neox", rot_dim=D, past_lens=[20])[0]
+    assert (torch.cat([a, b]).float() - whole.float()).abs().max().item() <= 2e-3
+    same = oracle.context_attention(rows, [S], Hq, Hkv, D, rope="neox", rot_dim=D, window=S,
+                                    alibi_slopes=torch.zeros(Hq).half())[0]
+    assert torch.equal(same, whole)
+    win = oracle.context_attention(rows, [S], Hq, Hkv, D, rope="neox", rot_dim=D, window=8)[0]
+    assert torch.equal(win[:9], whole[:9]) and not torch.equal(win[9:], whole[9:])  # rows 0..8 see every earlier key
+    # the cyclic append keeps the last `window` tokens at their slots (unfusedAttentionKernels_2_template.h:336-340)
+    cache2 = oracle.PagedKVCache(1, Hkv, D, 32, 16, torch.float16)
+    cmap = oracle.CyclicMap(16, 0, 16, cache2.max_blocks)
+    oracle.context_attention(rows, [S], Hq, Hkv, D, cache=cache2, window=16, cmap=cmap)
+    ref = oracle.PagedKVCache(1, Hkv, D, 64, 16, torch.float16)
+    oracle.context_attention(rows, [S], Hq, Hkv, D, cache=ref)
+    for t in range(S - 16, S):
+        assert torch.equal(cache2.gather(0, 0, 0, 32)[cmap.slot(t)], ref.gather(0, 0, 0, S)[t])
