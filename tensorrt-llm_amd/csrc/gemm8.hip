@@ -887,6 +887,20 @@ __global__ __launch_bounds__(512) void gemm8_direct_kernel(Gemm8Args g, int tile
     const size_t wj = (size_t) 16 * g.k;
     auto load_w = [&](i32x4_t (&fb)[4][2], int kt)
     {
+        if (abl & 4)
+        {
+            // abl bit 2: g.B holds the weights PRE-TILED in fragment order: block (n-tile of 16 rows, k-step of 64 bytes) =
+            // 1 KiB, lane l's 16 bytes at l * 16 -- one contiguous KiB per instruction (tools/lab_gemm8_direct.py tiles them)
+            const size_t ksteps = (size_t) g.k / 64;
+            const uint8_t* p = g.B + (((n0 >> 4) + wc * 4) * ksteps + (size_t) min(kt, nk - 1) * 2) * 1024 + lane * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[j][0]) : "v"(p + j * ksteps * 1024));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(fb[j][1]) : "v"(p + j * ksteps * 1024));
+            }
+            return;
+        }
         // abl bit 1: every tile re-reads tile 0's weights (same instruction count, always L2 / TCP hits; wrong results)
         const uint8_t* p = wsrc + ((abl & 2) ? 0 : (size_t) min(kt, nk - 1) * TK);
 #pragma unroll
