@@ -407,7 +407,7 @@ def bench_gated_act(dev, steps, tokens=4096, inter=13824, sets=6):
     return out
 
 
-def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16", past=0):
+def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64, kv="bf16", past=0, cached=False):
     """8f rank 1: context (prefill) attention, Llama-2-7B heads: bias-less RoPE + paged KV append + causal
     attention; flops counted on the causal half (2 * 2 * S^2/2 * D per head).  past > 0: chunked context -- the
     last S - past tokens of the sequence attend to all S keys through the paged cache."""
@@ -435,7 +435,7 @@ def bench_context_attention(dev, steps, B=4, H=32, Hkv=32, D=128, S=2048, tpb=64
     p.batch, p.num_heads, p.num_kv_heads, p.head_size = B, H, Hkv, D
     p.max_blocks_per_seq, p.tokens_per_block = S // tpb, tpb
     p.max_context_length, p.num_tokens, p.remove_padding = Sq, B * Sq, 0
-    if past:
+    if past or cached:   # (cached with past == 0: lab form -- K / V streamed back from the cache just written)
         p.sequence_lengths, p.max_kv_length = sl.data_ptr(), S
     p.act_type = L.BF16
     p.kv_type = {"bf16": L.BF16, "int8": L.INT8, "fp8": L.FP8}[kv]

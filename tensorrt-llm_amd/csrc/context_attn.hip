@@ -31,6 +31,7 @@ namespace
 typedef __attribute__((ext_vector_type(8))) __bf16 cbf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 cf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float cf32x4_t;
+typedef __attribute__((ext_vector_type(16))) float cf32x16_t;
 typedef __attribute__((ext_vector_type(4))) short cs16x4_t;
 typedef __attribute__((address_space(3))) cs16x4_t lds_cs16x4_t;
 typedef __attribute__((address_space(3))) void ctx_lds_void_t;
@@ -404,6 +405,19 @@ __device__ __forceinline__ cf32x4_t ctx_mfma<f16_t>(const uint4& a, const uint4&
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cf16x8_t, a), __builtin_bit_cast(cf16x8_t, b), c, 0, 0, 0);
 }
 
+template <typename T>
+__device__ __forceinline__ cf32x16_t ctx_mfma32(const uint4& a, const uint4& b, cf32x16_t c);
+template <>
+__device__ __forceinline__ cf32x16_t ctx_mfma32<bf16_t>(const uint4& a, const uint4& b, cf32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8_t, a), __builtin_bit_cast(cbf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ cf32x16_t ctx_mfma32<f16_t>(const uint4& a, const uint4& b, cf32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cf16x8_t, a), __builtin_bit_cast(cf16x8_t, b), c, 0, 0, 0);
+}
+
 constexpr int CTX_KT = 64;   // keys per tile
 constexpr int CTX_QW = 32;   // query rows per wave
 
@@ -411,7 +425,8 @@ constexpr int CTX_QW = 32;   // query rows per wave
 // long (many key tiles) workgroups are dispatched first.
 // CACHED: K / V of keys 0 .. kv_len - 1 come from the (16-bit) cache, the query rows sit at positions past .. (chunked
 // context); else from the workspace rows of this call (past = 0).  BIAS: ALiBi, scores biased before the softmax.
-template <typename T, int DH, int NWV, bool CACHED, bool BIAS>
+// W32: the 32x32x16 MFMA form (lane = one query column of the wave's 32, see compute32 below); else 16x16x32.
+template <typename T, int DH, int NWV, bool CACHED, bool BIAS, bool W32 = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 128 ? 1 : 2))) void ctx_attn_kernel(CtxArgs p)
 {
     constexpr int CTX_QB = CTX_QW * NWV;    // query rows per workgroup: 128 (4 waves, short sequences) / 256 (8 waves)
@@ -543,23 +558,41 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
     const int ntiles = (kv_end + CTX_KT - 1) / CTX_KT;
     const int tile_lo = max(past + Q0 - window, 0) / CTX_KT; // sliding window: first key the workgroup's first row sees
 
-    // Q^T fragments (B operand): column = query row q0 + 16*qt + lr, k = d = 32*ks + 8*lq + j
-    uint4 qf[2][KS];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    // Q^T fragments (B operand).  16x16x32: column = query row q0 + 16*qt + lr, k = d = 32*ks + 8*lq + j.
+    // 32x32x16: column = query row q0 + L, k = d = 16*ks + 8*hh + j  (L = lane & 31, hh = lane >> 5)
+    constexpr int KS16 = DH / 16, DB = DH / 32;
+    const int L = lane & 31, hh = lane >> 5;
+    uint4 qf[W32 ? 1 : 2][W32 ? 1 : KS];
+    uint4 qg[W32 ? KS16 : 1];
+    if constexpr (W32)
     {
-        const int qr = min(q0 + 16 * qt + lr, len - 1); // rows past the sequence re-read its last row; never stored
+        const int qr = min(q0 + L, len - 1); // rows past the sequence re-read its last row; never stored
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[qt][ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * DH + 32 * ks + 8 * lq);
+        for (int ks = 0; ks < KS16; ++ks)
+            qg[ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * DH + 16 * ks + 8 * hh);
+#pragma unroll
+        for (int ks = 0; ks < KS16; ++ks)
+            asm volatile("" : "+v"(qg[ks].x), "+v"(qg[ks].y), "+v"(qg[ks].z), "+v"(qg[ks].w));
     }
-    // make the compiler's own vmcnt bookkeeping for the Q loads end here, before any (invisible to it) DMA is in flight:
-    // otherwise it places its waits for them at their first use inside the loop, where they would drain the prefetch
+    else
+    {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < 2; ++qt)
+        {
+            const int qr = min(q0 + 16 * qt + lr, len - 1); // rows past the sequence re-read its last row; never stored
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            asm volatile("" : "+v"(qf[qt][ks].x), "+v"(qf[qt][ks].y), "+v"(qf[qt][ks].z), "+v"(qf[qt][ks].w));
+            for (int ks = 0; ks < KS; ++ks)
+                qf[qt][ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * DH + 32 * ks + 8 * lq);
+        }
+        // make the compiler's own vmcnt bookkeeping for the Q loads end here, before any (invisible to it) DMA is in
+        // flight: otherwise it places its waits for them at their first use inside the loop, where they would drain the
+        // prefetch
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                asm volatile("" : "+v"(qf[qt][ks].x), "+v"(qf[qt][ks].y), "+v"(qf[qt][ks].z), "+v"(qf[qt][ks].w));
+    }
     fetch_blocks(tile_lo);
     stage(tile_lo, tile_lo & 1);
     fetch_blocks(min(tile_lo + 1, ntiles - 1));
@@ -571,127 +604,252 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
         slope2 = T16<T>::to_float(p.alibi_slopes[h]) * 1.4426950408889634f;
 
     float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
-    cf32x4_t o[2][DT];
+    cf32x4_t o[W32 ? 1 : 2][W32 ? 1 : DT];
+    cf32x16_t o2[W32 ? DB : 1];
+    if constexpr (W32)
+    {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            o[qt][dt] = cf32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 16; ++i)
+                o2[db][i] = 0.f;
+    }
+    else
+    {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[qt][dt] = cf32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int rq = lr >> 2, rp = lr & 3;
     auto compute = [&](int buf, int t0)
     {
-        const uint8_t* kt = lds + buf * STAGE_BYTES;
-        const uint8_t* vt = kt + TILE_BYTES;
-        // ---- S^T tiles [key tile x][query tile qt]
-        cf32x4_t s[4][2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
+        if constexpr (!W32)
         {
-            const int row = 16 * x + lr;
-            uint4 kf[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                kf[ks] = *reinterpret_cast<const uint4*>(kt + ROWB * row + 16 * ((4 * ks + lq) ^ ksw(row)));
-#pragma unroll
+            const uint8_t* kt = lds + buf * STAGE_BYTES;
+            const uint8_t* vt = kt + TILE_BYTES;
+            // ---- S^T tiles [key tile x][query tile qt]
+            cf32x4_t s[4][2];
+    #pragma unroll
+            for (int x = 0; x < 4; ++x)
+            {
+                const int row = 16 * x + lr;
+                uint4 kf[KS];
+    #pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    kf[ks] = *reinterpret_cast<const uint4*>(kt + ROWB * row + 16 * ((4 * ks + lq) ^ ksw(row)));
+    #pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                {
+                    s[x][qt] = cf32x4_t{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        s[x][qt] = ctx_mfma<T>(kf[ks], qf[qt][ks], s[x][qt]);
+                }
+            }
+            // ---- mask (only tiles that cross the diagonal or the end of the sequence) + online softmax per query column.
+            // The running maximum is kept on the RAW scores (sscale > 0) and the scale rides in the exponent's fma:
+            // p = exp2(s * sscale - m * sscale)
+            const bool need_mask = t0 + CTX_KT - 1 > past + q0 || t0 + CTX_KT > kv_len
+                || t0 < past + q0 + CTX_QW - 1 - window; // wave-uniform: diagonal, end of the sequence, start of a row's window
+            uint4 pf[2][2];
+    #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
             {
-                s[x][qt] = cf32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    s[x][qt] = ctx_mfma<T>(kf[ks], qf[qt][ks], s[x][qt]);
+                const int qpos = past + q0 + 16 * qt + lr;
+                if constexpr (BIAS)
+                {
+    #pragma unroll
+                    for (int x = 0; x < 4; ++x)
+    #pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            s[x][qt][rr] = __builtin_fmaf(s[x][qt][rr], sscale_in, slope2 * (float) (t0 + 16 * x + 4 * lq + rr - qpos));
+                }
+                if (need_mask)
+                {
+                    // -inf, not NEG_BIG: a row whose keys of this tile are all masked (sliding window) keeps m_run = NEG_BIG,
+                    // and exp2(-inf - m_run) is still 0
+    #pragma unroll
+                    for (int x = 0; x < 4; ++x)
+    #pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                        {
+                            const int t = t0 + 16 * x + 4 * lq + rr;
+                            s[x][qt][rr] = (t <= qpos && t < kv_len && t >= qpos - window) ? s[x][qt][rr] : -__builtin_inff();
+                        }
+                }
+                float mx = ctx_max3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+                float my = ctx_max3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
+                mx = ctx_max3(mx, s[1][qt][2], s[1][qt][3]);
+                my = ctx_max3(my, s[2][qt][0], s[2][qt][1]);
+                mx = ctx_max3(mx, s[2][qt][2], s[2][qt][3]);
+                my = ctx_max3(my, s[3][qt][0], s[3][qt][1]);
+                mx = ctx_max3(mx, s[3][qt][2], s[3][qt][3]);
+                // all-reduce over the 4 lanes of the column (lane ^ 16, lane ^ 32) with the row-swap permutes: no LDS trip
+                mx = ctx_swap_max<16>(ctx_max3(mx, my, my));
+                const float m_new = ctx_max3(ctx_swap_max<32>(mx), m_run[qt], m_run[qt]);
+                if (__any(m_new > m_run[qt])) // wave-uniform: rescale only when some column's max moved
+                {
+                    const float corr = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sscale);
+                    m_run[qt] = m_new;
+                    l_run[qt] *= corr;
+    #pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+    #pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            o[qt][dt][rr] *= corr;
+                }
+                // a masked score is -inf: exp2(-inf + anything finite) = 0, also while m_run is still NEG_BIG
+                const float msc = -m_run[qt] * sscale;
+                float pr[4][4];
+                float ls = 0.f;
+    #pragma unroll
+                for (int x = 0; x < 4; ++x)
+    #pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                    {
+                        pr[x][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[x][qt][rr], sscale, msc));
+                        ls += pr[x][rr];
+                    }
+                l_run[qt] += ls;
+                // P^T fragments (B operand), one per 32 keys: k index j < 4 -> key 4*lq + j of tile 2kh, j >= 4 -> of tile 2kh+1
+    #pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+                    pf[qt][kh] = make_uint4(pack2<T>(pr[2 * kh][0], pr[2 * kh][1]), pack2<T>(pr[2 * kh][2], pr[2 * kh][3]),
+                        pack2<T>(pr[2 * kh + 1][0], pr[2 * kh + 1][1]), pack2<T>(pr[2 * kh + 1][2], pr[2 * kh + 1][3]));
             }
-        }
-        // ---- mask (only tiles that cross the diagonal or the end of the sequence) + online softmax per query column.
-        // The running maximum is kept on the RAW scores (sscale > 0) and the scale rides in the exponent's fma:
-        // p = exp2(s * sscale - m * sscale)
-        const bool need_mask = t0 + CTX_KT - 1 > past + q0 || t0 + CTX_KT > kv_len
-            || t0 < past + q0 + CTX_QW - 1 - window; // wave-uniform: diagonal, end of the sequence, start of a row's window
-        uint4 pf[2][2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+            // ---- O^T += V^T . P^T  (A operand rows d = 16*dt + lr).  Transposing read: lane 4q'+p' of a 16-lane group
+            // supplies row r0 + q', columns 4p' .. 4p'+3 of the 16-column block; lane i receives column i of rows r0 .. r0+3
+    #pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+            {
+                const int ra = 32 * kh + 4 * lq + rq, rb = ra + 16;
+    #pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                {
+                    const int ch = 2 * dt + (rp >> 1), sub = 8 * (rp & 1);
+                    const cs16x4_t va
+                        = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * ra + 16 * (ch ^ vsw(ra)) + sub));
+                    const cs16x4_t vb
+                        = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * rb + 16 * (ch ^ vsw(rb)) + sub));
+                    const uint2 a2 = __builtin_bit_cast(uint2, va), b2 = __builtin_bit_cast(uint2, vb);
+                    const uint4 vf = make_uint4(a2.x, a2.y, b2.x, b2.y);
+                    o[0][dt] = ctx_mfma<T>(vf, pf[0][kh], o[0][dt]);
+                    o[1][dt] = ctx_mfma<T>(vf, pf[1][kh], o[1][dt]);
+                }
+            }
+            }
+    };
+
+    // ---- the 32x32x16 form.  S^T = K . Q^T as two 32-key blocks x2: lane (L, hh) holds, for query column L, the keys
+    // 32*x2 + 8*(i/4) + 4*hh + i%4 (i < 16).  The 8 values i = 8*g2 .. 8*g2+7 are the B fragment (k = 8*hh + j) of
+    // k-step (x2, g2) of O^T += V^T . P^T, whose A fragment takes V rows r0 .. r0+3 and r0+8 .. r0+11,
+    // r0 = 32*x2 + 16*g2 + 4*hh, by two transposing reads.  O^T block db: d = 32*db + 8*(i/4) + 4*hh + i%4, column L.
+    auto compute32 = [&](int buf, int t0)
+    {
+        if constexpr (W32)
         {
-            const int qpos = past + q0 + 16 * qt + lr;
+            const uint8_t* kt = lds + buf * STAGE_BYTES;
+            const uint8_t* vt = kt + TILE_BYTES;
+            cf32x16_t s[2];
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    s[x2][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS16; ++ks)
+#pragma unroll
+                for (int x2 = 0; x2 < 2; ++x2)
+                {
+                    const int row = 32 * x2 + L;
+                    const uint4 kf = *reinterpret_cast<const uint4*>(kt + ROWB * row + 16 * ((2 * ks + hh) ^ ksw(row)));
+                    s[x2] = ctx_mfma32<T>(kf, qg[ks], s[x2]);
+                }
+            const bool need_mask = t0 + CTX_KT - 1 > past + q0 || t0 + CTX_KT > kv_len
+                || t0 < past + q0 + CTX_QW - 1 - window; // wave-uniform: diagonal, end of the sequence, start of a row's window
+            const int qpos = past + q0 + L;
             if constexpr (BIAS)
             {
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        s[x][qt][rr] = __builtin_fmaf(s[x][qt][rr], sscale_in, slope2 * (float) (t0 + 16 * x + 4 * lq + rr - qpos));
+                    for (int i = 0; i < 16; ++i)
+                        s[x2][i] = __builtin_fmaf(
+                            s[x2][i], sscale_in, slope2 * (float) (t0 + 32 * x2 + 8 * (i >> 2) + 4 * hh + (i & 3) - qpos));
             }
             if (need_mask)
             {
-                // -inf, not NEG_BIG: a row whose keys of this tile are all masked (sliding window) keeps m_run = NEG_BIG,
-                // and exp2(-inf - m_run) is still 0
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
+                    for (int i = 0; i < 16; ++i)
                     {
-                        const int t = t0 + 16 * x + 4 * lq + rr;
-                        s[x][qt][rr] = (t <= qpos && t < kv_len && t >= qpos - window) ? s[x][qt][rr] : -__builtin_inff();
+                        const int t = t0 + 32 * x2 + 8 * (i >> 2) + 4 * hh + (i & 3);
+                        s[x2][i] = (t <= qpos && t < kv_len && t >= qpos - window) ? s[x2][i] : -__builtin_inff();
                     }
             }
-            float mx = ctx_max3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
-            float my = ctx_max3(s[0][qt][3], s[1][qt][0], s[1][qt][1]);
-            mx = ctx_max3(mx, s[1][qt][2], s[1][qt][3]);
-            my = ctx_max3(my, s[2][qt][0], s[2][qt][1]);
-            mx = ctx_max3(mx, s[2][qt][2], s[2][qt][3]);
-            my = ctx_max3(my, s[3][qt][0], s[3][qt][1]);
-            mx = ctx_max3(mx, s[3][qt][2], s[3][qt][3]);
-            // all-reduce over the 4 lanes of the column (lane ^ 16, lane ^ 32) with the row-swap permutes: no LDS trip
-            mx = ctx_swap_max<16>(ctx_max3(mx, my, my));
-            const float m_new = ctx_max3(ctx_swap_max<32>(mx), m_run[qt], m_run[qt]);
-            if (__any(m_new > m_run[qt])) // wave-uniform: rescale only when some column's max moved
+            float mx = s[0][0], my = s[1][0];
+#pragma unroll
+            for (int i = 1; i < 15; i += 2)
             {
-                const float corr = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sscale);
-                m_run[qt] = m_new;
-                l_run[qt] *= corr;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        o[qt][dt][rr] *= corr;
+                mx = ctx_max3(mx, s[0][i], s[0][i + 1]);
+                my = ctx_max3(my, s[1][i], s[1][i + 1]);
             }
-            // a masked score is -inf: exp2(-inf + anything finite) = 0, also while m_run is still NEG_BIG
-            const float msc = -m_run[qt] * sscale;
-            float pr[4][4];
+            mx = ctx_max3(mx, my, s[0][15]);
+            mx = ctx_max3(mx, s[1][15], s[1][15]);
+            const float m_new = ctx_max3(ctx_swap_max<32>(mx), m_run[0], m_run[0]);
+            if (__any(m_new > m_run[0])) // wave-uniform: rescale only when some column's max moved
+            {
+                const float corr = __builtin_amdgcn_exp2f((m_run[0] - m_new) * sscale);
+                m_run[0] = m_new;
+                l_run[0] *= corr;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        o2[db][i] *= corr;
+            }
+            const float msc = -m_run[0] * sscale;
             float ls = 0.f;
+            uint4 pf[2][2];
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                {
-                    pr[x][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[x][qt][rr], sscale, msc));
-                    ls += pr[x][rr];
-                }
-            l_run[qt] += ls;
-            // P^T fragments (B operand), one per 32 keys: k index j < 4 -> key 4*lq + j of tile 2kh, j >= 4 -> of tile 2kh+1
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-                pf[qt][kh] = make_uint4(pack2<T>(pr[2 * kh][0], pr[2 * kh][1]), pack2<T>(pr[2 * kh][2], pr[2 * kh][3]),
-                    pack2<T>(pr[2 * kh + 1][0], pr[2 * kh + 1][1]), pack2<T>(pr[2 * kh + 1][2], pr[2 * kh + 1][3]));
-        }
-        // ---- O^T += V^T . P^T  (A operand rows d = 16*dt + lr).  Transposing read: lane 4q'+p' of a 16-lane group
-        // supplies row r0 + q', columns 4p' .. 4p'+3 of the 16-column block; lane i receives column i of rows r0 .. r0+3
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-        {
-            const int ra = 32 * kh + 4 * lq + rq, rb = ra + 16;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+            for (int x2 = 0; x2 < 2; ++x2)
             {
-                const int ch = 2 * dt + (rp >> 1), sub = 8 * (rp & 1);
-                const cs16x4_t va
-                    = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * ra + 16 * (ch ^ vsw(ra)) + sub));
-                const cs16x4_t vb
-                    = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * rb + 16 * (ch ^ vsw(rb)) + sub));
-                const uint2 a2 = __builtin_bit_cast(uint2, va), b2 = __builtin_bit_cast(uint2, vb);
-                const uint4 vf = make_uint4(a2.x, a2.y, b2.x, b2.y);
-                o[0][dt] = ctx_mfma<T>(vf, pf[0][kh], o[0][dt]);
-                o[1][dt] = ctx_mfma<T>(vf, pf[1][kh], o[1][dt]);
+                float pr[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                {
+                    pr[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[x2][i], sscale, msc));
+                    ls += pr[i];
+                }
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2)
+                    pf[x2][g2] = make_uint4(pack2<T>(pr[8 * g2], pr[8 * g2 + 1]), pack2<T>(pr[8 * g2 + 2], pr[8 * g2 + 3]),
+                        pack2<T>(pr[8 * g2 + 4], pr[8 * g2 + 5]), pack2<T>(pr[8 * g2 + 6], pr[8 * g2 + 7]));
             }
+            l_run[0] += ls;
+            const int cbl = (lane >> 4) & 1;
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2)
+                {
+                    const int ra = 32 * x2 + 16 * g2 + 4 * hh + rq, rb = ra + 8;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+                    {
+                        const int ch = 2 * (2 * db + cbl) + (rp >> 1), sub = 8 * (rp & 1);
+                        const cs16x4_t va
+                            = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * ra + 16 * (ch ^ vsw(ra)) + sub));
+                        const cs16x4_t vb
+                            = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_cs16x4_t*) (vt + ROWB * rb + 16 * (ch ^ vsw(rb)) + sub));
+                        const uint2 a2 = __builtin_bit_cast(uint2, va), b2 = __builtin_bit_cast(uint2, vb);
+                        o2[db] = ctx_mfma32<T>(make_uint4(a2.x, a2.y, b2.x, b2.y), pf[x2][g2], o2[db]);
+                    }
+                }
         }
     };
 
@@ -707,33 +865,64 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
         const int t0 = i * CTX_KT;
         // wave-uniform: tiles past this wave's last row, or before its first row's window, are fully masked
         if (wave_live && t0 < past + q0 + CTX_QW && t0 + CTX_KT > past + q0 - window)
-            compute(i & 1, t0);
+        {
+            if constexpr (W32)
+                compute32(i & 1, t0);
+            else
+                compute(i & 1, t0);
+        }
     }
 
     // ---- finish: sum over the 4 lanes of a column, normalise, store 4 consecutive d per lane
     if (!wave_live)
         return;
 
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    if constexpr (W32)
     {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16);
+        float l = l_run[0];
         l += __shfl_xor(l, 32);
         const float inv = 1.f / (l + 1e-6f);
-        const int qr = q0 + 16 * qt + lr;
+        const int qr = q0 + L;
         if (qr < len)
         {
             const int hs = p.head_size; // <= DH: columns past it are the zero padding of `proc`
             uint16_t* orow = p.out + (row0 + qr) * (size_t) (p.num_heads * hs) + (size_t) h * hs;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                if (16 * dt + 4 * lq < hs)
-                    *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * lq) = make_uint2(
-                        pack2<T>(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack2<T>(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                {
+                    const int d = 32 * db + 8 * g + 4 * hh;
+                    if (d < hs)
+                        *reinterpret_cast<uint2*>(orow + d) = make_uint2(pack2<T>(o2[db][4 * g] * inv, o2[db][4 * g + 1] * inv),
+                            pack2<T>(o2[db][4 * g + 2] * inv, o2[db][4 * g + 3] * inv));
+                }
+        }
+    }
+    else
+    {
+    #pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+        {
+            float l = l_run[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.f / (l + 1e-6f);
+            const int qr = q0 + 16 * qt + lr;
+            if (qr < len)
+            {
+                const int hs = p.head_size; // <= DH: columns past it are the zero padding of `proc`
+                uint16_t* orow = p.out + (row0 + qr) * (size_t) (p.num_heads * hs) + (size_t) h * hs;
+    #pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    if (16 * dt + 4 * lq < hs)
+                        *reinterpret_cast<uint2*>(orow + 16 * dt + 4 * lq) = make_uint2(
+                            pack2<T>(o[qt][dt][0] * inv, o[qt][dt][1] * inv), pack2<T>(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+            }
         }
     }
 }
+
 
 int ctx_ilog2(int x)
 {
@@ -892,7 +1081,20 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     // apart so that a SIMD's two waves alternate matrix and VALU segments -- measured 3-8 % slower: DESIGN.md 4.4)
     const dim3 agrid(q.num_heads, (q.max_context_length + 32 * 4 - 1) / (32 * 4), q.batch);
     const bool bias = a.alibi_slopes != nullptr;
+#ifdef MI355Q_LAB
+    // lab: the 32x32x16 form of the same kernel (measured: within -3 .. +3 % of the 16x16x32 form)
+    const bool w32 = lab_env("MI355Q_CTX_W32") != nullptr && dh_pad <= 128;
+#define MQ_CTX_LAUNCH2(TT, DD, CC, BB)                                                                                 \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (DD <= 128 && w32)                                                                                          \
+            hipLaunchKernelGGL((ctx_attn_kernel<TT, (DD <= 128 ? DD : 128), 4, CC, BB, true>), agrid, dim3(256), 0, stream, a); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((ctx_attn_kernel<TT, DD, 4, CC, BB, false>), agrid, dim3(256), 0, stream, a);           \
+    } while (0)
+#else
 #define MQ_CTX_LAUNCH2(TT, DD, CC, BB) hipLaunchKernelGGL((ctx_attn_kernel<TT, DD, 4, CC, BB>), agrid, dim3(256), 0, stream, a)
+#endif
 #define MQ_CTX_LAUNCH(TT, DD)                                                                                          \
     do                                                                                                                 \
     {                                                                                                                  \
