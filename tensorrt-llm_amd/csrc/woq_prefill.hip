@@ -24,6 +24,7 @@
 //     ends up with 4 consecutive output columns of one row: 8-byte stores, bias fused.
 #include "woq_common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace mi355q
@@ -47,15 +48,66 @@ __device__ __forceinline__ void pf_dma16(const void* base, uint32_t voff, uint32
                  : "memory", "m0");
 }
 
+template <int I>
+struct PfSlot
+{
+    static constexpr int value = I;
+};
+
+typedef uint32_t pf_u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ __forceinline__ void pf_lds_read(pf_u32x4_t& d, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// d is usable after this statement (N = LDS reads issued after the one that fills d)
+template <int N>
+__device__ __forceinline__ void pf_lds_wait(pf_u32x4_t& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N));
+}
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void pf_static_for(F&& f)
+{
+    if constexpr (I < N)
+    {
+        f(PfSlot<I>{});
+        pf_static_for<N, I + 1>(f);
+    }
+}
+
 struct PrefillPlan
 {
     int mt, nb, ksplit;
 };
 
+// 256 x 256 tiles on 8 waves (one workgroup per CU) against the 128-row tiles (two per CU): the big tile runs about
+// 1.15x faster per unit of work (tools/lab_pf256.py), either pays for a partly filled last round of workgroups.
+bool prefer_tile256(int64_t w256, int64_t w128)
+{
+    if (w256 <= 0)
+        return false;
+    const double r256 = (double) w256 / 256.0, r128 = (double) w128 / 512.0;
+    return 1.15 * r256 / std::ceil(r256) > r128 / std::ceil(r128);
+}
+
 PrefillPlan plan_prefill(int m, int n, int k, int wbits)
 {
     PrefillPlan p{};
     p.mt = m <= 32 ? 2 : (m <= 64 ? 4 : 8);
+    // 256 x 256 tiles on 8 waves once they alone fill the chip (one workgroup per CU); int4 only (the int8 form of that
+    // tile spills registers)
+    const bool lab_no256 = lab_env("MI355Q_PF_NO256") != nullptr; // (read per call: A/B in one process)
+    if (wbits == 4 && m >= 256 && n % 256 == 0 && ((m + 255) / 256) * (n / 256) >= 256 && !lab_no256
+        && prefer_tile256((int64_t) ((m + 255) / 256) * (n / 256), (int64_t) ((m + 127) / 128) * (n / 256)))
+    {
+        p.mt = 16;
+        p.nb = 2;
+        p.ksplit = 1;
+        return p;
+    }
     const int tiles_m = (m + p.mt * 16 - 1) / (p.mt * 16);
     // 256-column tiles (4 n-blocks per wave) once they alone fill the chip; else 128 columns
     p.nb = (p.mt == 8 && n % 256 == 0 && tiles_m * (n / 256) >= 256) ? 4 : 2;
@@ -73,20 +125,17 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
     return p;
 }
 
-template <int I>
-struct PfSlot
-{
-    static constexpr int value = I;
-};
-
 // grid.x = tiles_m * tiles_n (remapped XCD-contiguous, m fastest: neighbours share the weight panel)
+// NW: waves per workgroup.  4: tile (MT*16) x (NB*64), two workgroups per CU.  8: tile 256 x 256 (MT = 16, NB = 2), one
+// workgroup per CU (128 KiB of LDS for the int4 k-tile): every dequantised weight fragment then feeds 16 MFMAs instead
+// of 8, which halves the vector-ALU work per MFMA -- the dequantisation is what the matrix pipe waits for.
 // DEPTH: tiles of the k loop in flight + 1.  2 = ping-pong (one tile ahead: enough when a tile's MFMAs outlast a load);
 // 4 = a ring with three tiles ahead for the short tiles (MT <= 4, i.e. m <= 64 per workgroup: a tile is 16-32 MFMAs per
 // wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).
-template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2>
-__global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2, int NW = PF_WAVES>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
 {
-    constexpr int PF_TN = NB * 16 * PF_WAVES;
+    constexpr int PF_TN = NB * 16 * NW;
     constexpr int KTILE = Geo<WBITS>::KTILE;   // 128 (int4) / 64 (int8) rows of k per weight tile
     constexpr int KSTEPS = Geo<WBITS>::KSTEPS; // MFMA k-steps per tile
     constexpr int TM = MT * 16;
@@ -95,8 +144,8 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     constexpr int ROWS_PER_DMA = 1024 / RB;    // 4 / 8
     constexpr int BUF_BYTES = TM * RB;
     constexpr int DMA_PER_TILE = BUF_BYTES / 1024;
-    constexpr int DMA_PER_WAVE = (DMA_PER_TILE + PF_WAVES - 1) / PF_WAVES;
-    static_assert(DEPTH == 2 || DMA_PER_TILE % PF_WAVES == 0, "the ring counts its loads: every wave must issue the same number");
+    constexpr int DMA_PER_WAVE = (DMA_PER_TILE + NW - 1) / NW;
+    static_assert(DEPTH == 2 || DMA_PER_TILE % NW == 0, "the ring counts its loads: every wave must issue the same number");
     __shared__ __attribute__((aligned(1024))) uint8_t lds[DEPTH * BUF_BYTES];
 
     const int tid = threadIdx.x;
@@ -169,7 +218,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
         for (int i = 0; i < DMA_PER_WAVE; ++i)
         {
             const int d = wave * DMA_PER_WAVE + i;
-            if (DMA_PER_TILE % PF_WAVES != 0 && d >= DMA_PER_TILE)
+            if (DMA_PER_TILE % NW != 0 && d >= DMA_PER_TILE)
                 continue;
             pf_dma16(act_base, aoff[i] + kt * (KTILE * 2), lds_base + buf * BUF_BYTES + d * 1024);
         }
@@ -180,7 +229,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
         for (int i = 0; i < DMA_PER_WAVE; ++i)
         {
             const int d = wave * DMA_PER_WAVE + i;
-            if (DMA_PER_TILE % PF_WAVES != 0 && d >= DMA_PER_TILE)
+            if (DMA_PER_TILE % NW != 0 && d >= DMA_PER_TILE)
                 continue;
             const int achunk = dchunk ^ sw(d * ROWS_PER_DMA + drow);
             const uint32_t back = achunk * 8 >= 64 ? achunk * 16 : 0;
@@ -304,14 +353,31 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
                     wf[b] = dequant_step<T, WBITS, 3 % KSTEPS>(t.w[b], s[b][h], z[b][h]);
             }
             const int coff = ((st * 4 + fk) ^ fsw) << 4;
+            // Activation fragments run AF m-blocks ahead of the MFMAs that use them, in a ring of AF + 1 register quads,
+            // read and waited for from inline asm: left to itself hipcc reads every fragment into the SAME quad right in
+            // front of its MFMAs (ds_read, lgkmcnt(0), NB MFMAs, ds_read ...), so every group of NB MFMAs starts with an
+            // exposed LDS round trip -- that, not the dequantisation, kept the matrix pipe at half rate.  The LDS returns
+            // in order: "fragment j has landed" = at most (reads issued after it) outstanding.
+            // (distance: about one LDS round trip of MFMAs -- 4 groups of NB = 2, 2 of NB = 4; 1 where the second
+            // scale / zero set of group size 64 leaves no registers)
+            constexpr int AFW = NB == 2 ? 4 : (NSZ == 2 ? 1 : 2);
+            constexpr int AF = MT - 1 < AFW ? MT - 1 : AFW, R = AF + 1;
+            const uint32_t abase = (uint32_t) (uintptr_t) (lds_void_t*) sa + (uint32_t) coff;
+            pf_u32x4_t av[R];
+            pf_static_for<AF>([&](auto jc) { pf_lds_read<decltype(jc)::value * 16 * RB>(av[decltype(jc)::value % R], abase); });
+            pf_static_for<MT>(
+                [&](auto jc)
+                {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j + AF < MT)
+                        pf_lds_read<(j + AF) * 16 * RB>(av[(j + AF) % R], abase);
+                    constexpr int issued = j + AF < MT ? j + 1 + AF : MT;
+                    pf_lds_wait<issued - (j + 1)>(av[j % R]);
+                    const uint4 af = __builtin_bit_cast(uint4, av[j % R]);
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
-            {
-                const uint4 av = *reinterpret_cast<const uint4*>(sa + j * 16 * RB + coff);
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    acc[b][j] = mfma16<T>(wf[b], av, acc[b][j]);
-            }
+                    for (int b = 0; b < NB; ++b)
+                        acc[b][j] = mfma16<T>(wf[b], af, acc[b][j]);
+                });
         }
     };
 
@@ -438,14 +504,14 @@ __global__ __launch_bounds__(PF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
-template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB>
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int NW = PF_WAVES>
 void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
 {
-    const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 64);
+    const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 16 * NW);
     // (the 4-slot ring of the grouped MoE launch was measured here too, m = 40 - 64 at seven Llama shapes: 2 - 17 %
     // SLOWER than the ping-pong -- these launches are split over K into 4-tile pieces, a ring never fills)
-    hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB>), dim3(tiles_m * tiles_n, a.ksplit),
-        dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB, 2, NW>), dim3(tiles_m * tiles_n, a.ksplit),
+        dim3(NW * 64), 0, stream, a, tiles_m, tiles_n);
 }
 
 template <typename T, int WBITS, bool ZERO>
@@ -462,7 +528,17 @@ void launch_prefill(const WoqArgs& a, hipStream_t stream)
         else                                                                                                           \
             launch_prefill_mt<T, WBITS, ZERO, 1, MTV, NBV>(a, stream);                                                 \
     } while (0)
-    if (p.mt == 2)
+    if (p.mt == 16)
+    {
+        if constexpr (WBITS == 4)
+        {
+            if (split)
+                launch_prefill_mt<T, WBITS, ZERO, NSZ2, 16, 2, 8>(a, stream);
+            else
+                launch_prefill_mt<T, WBITS, ZERO, 1, 16, 2, 8>(a, stream);
+        }
+    }
+    else if (p.mt == 2)
         MQ_PF(2, 2);
     else if (p.mt == 4)
         MQ_PF(4, 2);
@@ -582,10 +658,26 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     a.moe_wbytes = (size_t) p.gemm_n * p.gemm_k * (i4 ? 1 : 2) / 2;
     // tile height from the average rows per expert (the host does not know the split)
     const int64_t avg = (p.total_rows + p.num_experts - 1) / p.num_experts;
-    const int mt = avg <= 32 ? 2 : (avg <= 64 ? 4 : 8);
+    int mt = avg <= 32 ? 2 : (avg <= 64 ? 4 : 8);
+    const bool bf = p.act_type == MI355Q_BF16;
+    // prefill-sized experts (int4): 256 x 256 tiles on 8 waves, as in the dense launch
+    if (i4 && avg >= 256 && a.n % 256 == 0 && a.ksplit == 1 && !lab_env("MI355Q_PF_NO256")
+        && prefer_tile256(((p.total_rows + 255) / 256 + p.num_experts / 2) * (a.n / 256),
+            ((p.total_rows + 127) / 128 + p.num_experts / 2) * (a.n / 128)))
+    {
+        mt = 16;
+        const int tm16 = (int) ((p.total_rows + 255) / 256) + p.num_experts, tn16 = a.n / 256;
+        if (bf)
+            hipLaunchKernelGGL((woq_prefill_kernel<bf16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream, a,
+                tm16, tn16);
+        else
+            hipLaunchKernelGGL((woq_prefill_kernel<f16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream, a,
+                tm16, tn16);
+        MQ_HIP(hipGetLastError());
+        return;
+    }
     const int tiles_m = (int) ((p.total_rows + mt * 16 - 1) / (mt * 16)) + p.num_experts;
     const int tiles_n = a.n / 128;
-    const bool bf = p.act_type == MI355Q_BF16;
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
