@@ -335,6 +335,19 @@ def bench_prefill_w4a16(dev, steps, m=4096, n=11008, k=4096, g=128):
             "frac_of_bf16_peak": ops / (dev_s / steps) / 1e12 / 2500.0}
 
 
+def bench_prefill_w8a16(dev, steps, m=4096, n=11008, k=4096):
+    """a2 at prefill size: W8A16 per-channel GEMM through the WeightOnlyQuantMatmul plugin (int8 weights, bf16)."""
+    from mi355q import functional as F
+    torch.manual_seed(0)
+    w = torch.randint(-128, 128, (k, n), dtype=torch.int8, device=dev)
+    sc = torch.rand(n, dtype=torch.bfloat16, device=dev)
+    x = torch.randn(m, k, dtype=torch.bfloat16, device=dev)
+    _, dev_s = time_steps(lambda: F.weight_only_quant_matmul(x, w, sc, 1, "bfloat16"), steps, 2, lambda: None)
+    ops = 2.0 * m * n * k
+    return {"m": m, "n": n, "k": k, "weights": "int8 per-channel", "ms_per_call": dev_s / steps * 1e3,
+            "TFLOPS": ops / (dev_s / steps) / 1e12, "frac_of_bf16_peak": ops / (dev_s / steps) / 1e12 / 2500.0}
+
+
 def bench_rmsnorm_quant(dev, steps, tokens=4096, hidden=5120, sets=24):
     """8f rank 2: RMSNorm + dynamic per-token int8 quantisation, the cfg3 GEMM's feeder (Llama-2-13B hidden).
     Algorithmic bytes per call: tokens*hidden*(2 in + 1 out) + hidden*2*2 (gamma, beta) + tokens*4 (scales);
@@ -722,6 +735,7 @@ def main():
                                             bench_context_attention(dev, 10, B=2, H=64, Hkv=8, S=4096, kv="fp8"),
                                             bench_context_attention(dev, 10, B=4, S=4096, past=2048)]
                 sec["w4a16_prefill_gemm"] = [bench_prefill_w4a16(dev, 10), bench_prefill_w4a16(dev, 10, n=4096, k=11008)]
+                sec["w8a16_prefill_gemm"] = [bench_prefill_w8a16(dev, 10), bench_prefill_w8a16(dev, 10, n=4096, k=11008)]
                 sec["moe_w4_grouped_gemm"] = [bench_moe_gemm(dev, 10, tokens=64), bench_moe_gemm(dev, 10, tokens=4096)]
                 sec["moe_w4_layer"] = [bench_moe_layer(dev, 10, tokens=64), bench_moe_layer(dev, 10, tokens=4096)]
             except Exception as e:  # secondary numbers must never take the headline down

@@ -110,7 +110,9 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
     }
     const int tiles_m = (m + p.mt * 16 - 1) / (p.mt * 16);
     // 256-column tiles (4 n-blocks per wave) once they alone fill the chip; else 128 columns
-    p.nb = (p.mt == 8 && n % 256 == 0 && tiles_m * (n / 256) >= 256) ? 4 : 2;
+    // (int8 weights: the 4-n-block instantiation spills ~140 registers per lane into scratch inside the k loop and ran
+    // at 120 TFLOP/s -- tools/lab_w8_prefill.py; 2 n-blocks fit)
+    p.nb = (wbits == 4 && p.mt == 8 && n % 256 == 0 && tiles_m * (n / 256) >= 256) ? 4 : 2;
     const int wgs = tiles_m * (n / (p.nb * 64));
     const int nk = (k + (wbits == 4 ? 127 : 63)) / (wbits == 4 ? 128 : 64);
     // split K while the output tiles leave most CUs idle (fp32 slabs + reduce launch): >= 4 k-tiles per split
@@ -542,10 +544,13 @@ void launch_prefill(const WoqArgs& a, hipStream_t stream)
         MQ_PF(2, 2);
     else if (p.mt == 4)
         MQ_PF(4, 2);
-    else if (p.nb == 2)
+    else if (p.nb == 2 || WBITS != 4)
         MQ_PF(8, 2);
     else
-        MQ_PF(8, 4);
+    {
+        if constexpr (WBITS == 4)
+            MQ_PF(8, 4);
+    }
 #undef MQ_PF
 }
 
