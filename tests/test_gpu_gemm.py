@@ -112,6 +112,16 @@ def test_groupwise_two_row_chunks_large_k(cuda, m):
     _groupwise_case(m, 2048, 8192, "bfloat16", False, True, True, 128, cuda)
 
 
+@pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
+@pytest.mark.parametrize("m,n,k,pre,zero,bias,gs", [(512, 32768, 256, False, True, False, 128),
+                                                    (300, 32768, 320, True, True, True, 64),
+                                                    (1024, 16384, 192, False, False, True, 64)])
+def test_groupwise_prefill_big_tile(cuda, dtype_str, m, n, k, pre, zero, bias, gs):
+    # m >= 256 with enough 256 x 256 tiles to fill the chip: the 8-wave tile of the prefill kernel (ragged last m-tile,
+    # int4 half k-tile, both scale-group forms)
+    _groupwise_case(m, n, k, dtype_str, pre, zero, bias, gs, cuda)
+
+
 def test_groupwise_empty_batch(cuda):
     dt = torch.float16
     w = torch.zeros(64, 16, dtype=dt, device=cuda)

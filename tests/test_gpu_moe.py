@@ -70,5 +70,13 @@ def test_moe_gemm_decode_and_prefill_row_counts(cuda):
     _case(cuda, [400, 130, 0, 257, 64, 512, 1, 300], 512, 512, "float16", L.WEIGHT_INT8, "silu", True)
 
 
+@pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
+def test_moe_gemm_prefill_sized_experts_big_tile(cuda, dtype_str):
+    # >= 256 rows per expert on average, int4, n large enough for prefer_tile256: the 256 x 256 / 8-wave tile of the
+    # grouped launch; ragged experts (one empty, one of a single row, one straddling two tiles), bias + activation epilogue
+    _case(cuda, [600, 0, 1, 423], 8192, 128, dtype_str, L.WEIGHT_INT4, "identity", False)
+    _case(cuda, [257, 511, 300], 8192, 192, dtype_str, L.WEIGHT_INT4, "silu", True)
+
+
 def test_moe_gemm_no_rows(cuda):
     _case(cuda, [0, 0, 0], 128, 128, "float16", L.WEIGHT_INT8, "identity", False)
