@@ -427,8 +427,10 @@ MoeLayout moe_layout(const mi355q_moe_params& p)
     l.fc1 = take(n * p.inter_size * 2);
     l.glu = take(l.gated ? n * p.inter_size * 4 : 0);
     l.fc2 = take(n * p.hidden_size * 2);
-    // decode-sized calls: fp32 slabs for a split-K w2 GEMM (few n-tiles, long k), up to 8 splits
-    l.slab_bytes = n <= 512 ? 8 * n * p.hidden_size * sizeof(float) : 0;
+    // fp32 slabs for a split-K w2 GEMM (few n-tiles, long k) while its tiles leave CUs idle: up to 8 splits for
+    // decode-sized calls, 4 / 2 up to 1024 / 2048 expanded rows (the same bytes at every size)
+    const size_t splits = n <= 512 ? 8 : (n <= 1024 ? 4 : (n <= 2048 ? 2 : 0));
+    l.slab_bytes = splits * n * p.hidden_size * sizeof(float);
     l.slabs = take(l.slab_bytes);
     l.total = off;
     return l;

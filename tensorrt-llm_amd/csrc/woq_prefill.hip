@@ -132,8 +132,10 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
 // workgroup per CU (128 KiB of LDS for the int4 k-tile): every dequantised weight fragment then feeds 16 MFMAs instead
 // of 8, which halves the vector-ALU work per MFMA -- the dequantisation is what the matrix pipe waits for.
 // DEPTH: tiles of the k loop in flight + 1.  2 = ping-pong (one tile ahead: enough when a tile's MFMAs outlast a load);
-// 4 = a ring with three tiles ahead for the short tiles (MT <= 4, i.e. m <= 64 per workgroup: a tile is 16-32 MFMAs per
-// wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).
+// 4 = a ring with three tiles ahead for the shortest tiles (MT = 2, i.e. 32 rows per workgroup: a tile is 16 MFMAs per
+// wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).  At
+// MT = 4 the ring's 64 KiB of LDS leave 2 workgroups per CU where the ping-pong has 5, and the ping-pong wins (grouped
+// MoE launch, 64 rows per expert: 167 against 192 us, tools/lab_moe_depth.py).
 template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2, int NW = PF_WAVES>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
 {
@@ -600,6 +602,39 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
     MQ_HIP(hipGetLastError());
 }
 
+// Tile height of the grouped MoE launch.  The host sees only the total row count, but with real routing the experts'
+// row counts scatter around the average (about a binomial: sigma^2 ~ avg (1 - 1/experts)), and a workgroup tile that the
+// average fills exactly is half wasted on every expert that got a few rows more.  Expected padded rows per expert
+// E[ceil(r / TM)] TM for r ~ N(avg, sigma^2), weighted by how well each tile height runs (tools/lab_moe_mt.py: 64-row
+// tiles 0.87, 128-row 1.0, the 256 x 256 / 8-wave tile 1.16); 32-row tiles (with their deeper ring) while the launch is a
+// weight stream (<= 24 rows per expert).
+double moe_expected_padded_rows(double avg, double sigma, int tm)
+{
+    auto cdf = [&](double x) { return 0.5 * (1.0 + std::erf((x - avg) / (sigma * 1.4142135623730951))); };
+    const int j0 = std::max(1, (int) std::floor((avg - 5 * sigma) / tm)), j1 = (int) std::ceil((avg + 5 * sigma) / tm) + 1;
+    double e = 0.0, mass = 0.0;
+    for (int j = j0; j <= j1; ++j)
+    {
+        const double pj = cdf((double) j * tm) - cdf((double) (j - 1) * tm);
+        e += pj * j * tm;
+        mass += pj;
+    }
+    return mass > 0 ? e / mass : avg;
+}
+
+int moe_pick_tile(int64_t total_rows, int experts, bool allow256)
+{
+    const double avg = (double) total_rows / experts;
+    if (avg <= 24.0)
+        return 2;
+    const double sigma = std::sqrt(std::max(1.0, avg * (1.0 - 1.0 / std::max(2, experts))));
+    const double c4 = moe_expected_padded_rows(avg, sigma, 64) / 0.87, c8 = moe_expected_padded_rows(avg, sigma, 128);
+    const double c16 = allow256 ? moe_expected_padded_rows(avg, sigma, 256) / 1.16 : 1e30;
+    if (c16 < c8 && c16 < c4)
+        return 16;
+    return c4 < c8 ? 4 : 8;
+}
+
 // The expert GEMMs of a mixture-of-experts layer with weight-only quantised experts, as ONE launch
 // (MoeGemmRunner<T, uint8_t | cutlass::uint4b_t>::moeGemmBiasAct, kernels/cutlass_kernels/moe_gemm/moe_gemm_kernels.h:51-58,
 // moe_gemm_kernels_template.h:401-470; the reference runs a CUTLASS grouped GEMM whose problem sizes a kernel derives
@@ -638,12 +673,21 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     a.ktiles = a.k / (i4 ? 128 : 64);
     a.ksplit = 1;
     a.act_fn = p.activation_type;
-    // split K over grid.y while the tiles leave most CUs idle (decode: the w2 GEMM has few n-tiles and a long k):
-    // fp32 slabs in the caller's workspace + the reduce launch; only without bias / activation (moeGemm), whose
-    // epilogue the reduce kernel then is
+    // tile height from the average rows per expert (the host does not know the split)
+    const bool allow256 = i4 && p.gemm_n % 256 == 0 && !lab_env("MI355Q_PF_NO256");
+    int mt = moe_pick_tile(p.total_rows, p.num_experts, allow256);
+    if (const char* e = lab_env("MI355Q_MOE_MT")) // lab: force the tile height (2 / 4 / 8 m-blocks)
+        mt = atoi(e);
+    const bool want256 = mt == 16;
+    if (want256)
+        mt = 8; // (the split-K estimate below and the fallback when the 256-row tile's rounds fill the chip badly)
+    // split K over grid.y while the tiles leave most CUs idle (the w2 GEMM has few n-tiles and a long k: at 512 tokens
+    // its 256 live workgroups each walked 112 k-tiles and the GEMM took 3x the w1|w3 GEMM's time per flop): fp32 slabs in
+    // the caller's workspace + the reduce launch; only without bias / activation (moeGemm), whose epilogue the reduce
+    // kernel then is.  Workgroups counted at the tile height actually used (+ half a tile per expert for the ragged ends).
     {
         const int ktiles = (int) (p.gemm_k / (i4 ? 128 : 64));
-        const int64_t wgs = (p.gemm_n / 128) * ((p.total_rows + 31) / 32 + p.num_experts);
+        const int64_t wgs = (p.gemm_n / 128) * ((p.total_rows + mt * 16 - 1) / (mt * 16) + (p.num_experts + 1) / 2);
         int ks = 1;
         if (p.splitk_workspace && !p.biases && p.activation_type == 5 && wgs < 768 && ktiles >= 16)
         {
@@ -661,12 +705,9 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     a.moe_rows = p.total_rows_before_expert;
     a.moe_experts = p.num_experts;
     a.moe_wbytes = (size_t) p.gemm_n * p.gemm_k * (i4 ? 1 : 2) / 2;
-    // tile height from the average rows per expert (the host does not know the split)
-    const int64_t avg = (p.total_rows + p.num_experts - 1) / p.num_experts;
-    int mt = avg <= 32 ? 2 : (avg <= 64 ? 4 : 8);
     const bool bf = p.act_type == MI355Q_BF16;
     // prefill-sized experts (int4): 256 x 256 tiles on 8 waves, as in the dense launch
-    if (i4 && avg >= 256 && a.n % 256 == 0 && a.ksplit == 1 && !lab_env("MI355Q_PF_NO256")
+    if (want256 && a.ksplit == 1
         && prefer_tile256(((p.total_rows + 255) / 256 + p.num_experts / 2) * (a.n / 256),
             ((p.total_rows + 127) / 128 + p.num_experts / 2) * (a.n / 128)))
     {
@@ -686,8 +727,8 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (MTV <= 4 && !lab_env("MI355Q_PF_DEPTH2"))                                                                  \
-            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 4 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \
+        if (MTV <= 2 && !lab_env("MI355Q_PF_DEPTH2"))                                                                  \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \
                 dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);                                                  \
         else                                                                                                           \
             hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2>), dim3(tiles_m * tiles_n, a.ksplit),       \
