@@ -227,8 +227,9 @@ extern "C"
         int32_t activation_type;   /* ActivationType (moe_gemm_kernels.h:27-36): 0 Gelu, 1 Relu, 2 Silu, 5 Identity */
         int32_t weight_type;       /* MI355Q_WEIGHT_INT8 / INT4 */
         int32_t act_type;          /* MI355Q_HALF / MI355Q_BF16 */
-        /* optional: fp32 scratch that lets the GEMM split K over workgroups when the rows are few (decode) and it has
-         * neither bias nor activation; splits * total_rows * gemm_n * 4 bytes are used, at most 8 splits; NULL = never */
+        /* optional: fp32 scratch that lets the GEMM split K over workgroups while its output tiles leave most CUs idle
+         * (few rows, or few n-tiles and a long k) and it has neither bias nor activation; splits * total_rows * gemm_n * 4
+         * bytes are used, at most 8 splits, fewer if the scratch is smaller; NULL = never */
         void* splitk_workspace;
         size_t splitk_workspace_bytes;
     } mi355q_moe_gemm_params;
