@@ -190,7 +190,7 @@ __global__ __launch_bounds__(LW * 64) void woq_gemv_light_kernel(LightArgs p)
 {
     constexpr int KTILE = Geo<WBITS>::KTILE;
     constexpr int KS = Geo<WBITS>::KSTEPS;
-    constexpr int AV = LightGeo<WBITS, MF>::AV, PV = LightGeo<WBITS, MF>::PV;
+    constexpr int AV = LightGeo<WBITS, MF>::AV;
     constexpr int ROWS = MF == 2 ? 16 : 4 * (MF + 1);
     const WoqArgs& a = p.a;
     __shared__ float red[MF == 2 ? LW * 256 : LW * ROWS * 16];
