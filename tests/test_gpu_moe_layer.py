@@ -88,6 +88,13 @@ def test_moe_layer_many_experts_and_edge_rows(cuda):
     run_case(cuda, 1025, 128, 128, 8, 2, torch.float16, L.WEIGHT_INT8, "identity")               # one pair into a second chunk
 
 
+@pytest.mark.parametrize("rows,wtype", [(60, L.WEIGHT_INT4), (400, L.WEIGHT_INT4), (400, L.WEIGHT_INT8), (900, L.WEIGHT_INT4)])
+def test_moe_layer_w2_split_k(cuda, rows, wtype):
+    # a long inter_size against a narrow hidden_size: the w2 GEMM has few n-tiles and >= 16 k-tiles, so it splits K over
+    # workgroups through the fp32 slabs of the workspace (8 / 4 / 2 splits allowed up to 512 / 1024 / 2048 expanded rows)
+    run_case(cuda, rows, 512, 4096, 8, 2, torch.bfloat16, wtype, "swiglu", renorm=True, seed=5)
+
+
 def test_moe_layer_finished_rows_and_parallelism(cuda):
     fin = [i % 3 == 0 for i in range(90)]
     out, _, _ = run_case(cuda, 90, 128, 256, 8, 2, torch.float16, L.WEIGHT_INT8, "swiglu", finished=fin, with_bias=True)
