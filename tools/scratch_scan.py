@@ -8,9 +8,11 @@ root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 extra = sys.argv[1:]
 bad = 0
 for src in sorted(glob.glob(os.path.join(root, "*.hip"))):
+    # the Makefile's per-file flags (SLP off for the weight-only GEMMs)
+    per_file = ["-fno-slp-vectorize"] if os.path.basename(src) in ("woq_gemm.hip", "woq_gemv_small.hip", "woq_prefill.hip") else []
     with tempfile.TemporaryDirectory() as td:
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-                            "-Rpass-analysis=kernel-resource-usage", *extra, "-c", src, "-o", os.path.join(td, "x.o")],
+                            "-Rpass-analysis=kernel-resource-usage", *per_file, *extra, "-c", src, "-o", os.path.join(td, "x.o")],
                            capture_output=True, text=True, cwd=root)
     seen = set()
     for blk in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
