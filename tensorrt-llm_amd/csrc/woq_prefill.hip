@@ -4,7 +4,7 @@
 //   dequant-in-mainloop tensor-op GEMM the plugins pick for m >= 5).
 // Design (MFMA-bound):
 //   * output tile TM (= MT*16: 32 / 64 / 128 rows of m) x TN (= NB*64: 128 / 256 columns) per workgroup
-//     of 4 waves; wave w owns the NB 16-column n-blocks NB*w .. NB*w+NB-1 of the tile and ALL its m
+//     of 4 waves (or 256 x 256 on 8 waves for large int4 problems, template parameter NW); wave w owns the NB 16-column n-blocks NB*w .. NB*w+NB-1 of the tile and ALL its m
 //     rows, so every weight is dequantised exactly once per workgroup (23 VALU ops per 8 weights) and
 //     reused by MT MFMAs, and every activation fragment read from LDS feeds NB MFMAs (NB = 4 keeps the
 //     LDS read pipe at half the MFMA pipe's time; NB = 2 would tie them);
@@ -130,7 +130,8 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
 // grid.x = tiles_m * tiles_n (remapped XCD-contiguous, m fastest: neighbours share the weight panel)
 // NW: waves per workgroup.  4: tile (MT*16) x (NB*64), two workgroups per CU.  8: tile 256 x 256 (MT = 16, NB = 2), one
 // workgroup per CU (128 KiB of LDS for the int4 k-tile): every dequantised weight fragment then feeds 16 MFMAs instead
-// of 8, which halves the vector-ALU work per MFMA -- the dequantisation is what the matrix pipe waits for.
+// of 8, which halves the vector-ALU work per MFMA (worth 5 - 13 % once the activation fragment reads stopped being
+// serialised, see compute()).
 // DEPTH: tiles of the k loop in flight + 1.  2 = ping-pong (one tile ahead: enough when a tile's MFMAs outlast a load);
 // 4 = a ring with three tiles ahead for the shortest tiles (MT = 2, i.e. 32 rows per workgroup: a tile is 16 MFMAs per
 // wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).  At
