@@ -102,7 +102,10 @@ extern "C"
      *   "LayernormQuantization"          {eps, use_diff_of_squares, dyn_act_scaling, type_id}
      *        plugins/layernormQuantizationPlugin/layernormQuantizationPlugin.cpp:233-302
      *   "AllReduce"                      {group, type_id, strategy, counter} (+ optional "rank")
-     *        plugins/ncclPlugin/allreducePlugin.cpp:141-203, 286-350 (one-shot / two-shot; RING is the host's RCCL call)
+     *        plugins/ncclPlugin/allreducePlugin.cpp:141-203, 286-350 (one-shot / two-shot push kernels; RING and AUTO
+     *        beyond the comm buffers = ncclAllReduce on the group's communicator, mi355q_comm_init_rank)
+     *   "AllGather"                      {group, type_id} plugins/ncclPlugin/allgatherPlugin.cpp:90-110, 190-230
+     *        (one input: ncclAllGather; with the AllReduce workspace table as second input: the push kernel)
      *   "Fp8Gemm"  (no reference plugin: TensorRT fuses Q/DQ+matmul) {type_id}
      * Weight tensors handed to enqueue are in the layout mi355q_preprocess_weights_for_mixed_gemm
      * produces for MI355Q_LAYOUT_GFX950 (the arch-selected layout, as the reference selects per SM). */
@@ -457,12 +460,17 @@ extern "C"
 #define MI355Q_IPC_HANDLE_BYTES 64  /* sizeof(hipIpcMemHandle_t) */
 #define MI355Q_AR_MAX_WORKGROUPS 256 /* one per CU (the reference: MAX_ALL_REDUCE_BLOCKS = 24, customAllReduceKernels.h:32) */
     /* bytes of ONE barrier-flag array (barrier-in or barrier-out) per rank: flags are per (phase, source rank,
-     * workgroup); replaces IPC_BARRIERS_SIZE_PER_GPU of tensorrt_llm/_ipc_utils.py */
+     * workgroup), followed by the rank's own epoch and arrival words (the kernels derive the flag value and the
+     * ping / pong parity of a call from that device-resident epoch, so plugins that replay the same build-time
+     * `counter` on every pass -- an engine, a hipGraph -- stay synchronised); replaces IPC_BARRIERS_SIZE_PER_GPU of
+     * tensorrt_llm/_ipc_utils.py.  The arrays must be zeroed once, at allocation (mi355q_ipc_alloc does). */
     size_t mi355q_allreduce_barrier_bytes(void);
     /* kernels/customAllReduceKernels.h:44-58 AllReduceParams, plus what the MI355X kernels add (trailing fields):
      * the input where it lies (they push it to the peers themselves: no staging copy), the byte size of a comm buffer
-     * (checked against the message), a host-visible word that receives 1 when a peer never arrived (or NULL) and the
-     * wall-clock bound of every wait in milliseconds (0 = 2000). */
+     * (checked against the message), a host-visible word that receives 1 when a peer never arrived (or NULL), the
+     * wall-clock bound of every wait in milliseconds (0 = 30000), and BOTH sets of comm buffers: the kernels choose
+     * ping or pong by their own epoch, barrier_flag / peer_comm_buffer_ptrs keep the reference's meaning and are not
+     * read by them.  All ranks must issue the same sequence of collectives on these buffers, one stream at a time. */
     typedef struct
     {
         size_t elts_total;
@@ -479,6 +487,8 @@ extern "C"
         const void* local_input_buffer_ptr;
         size_t comm_buffer_bytes; /* 0 = mi355q_allreduce_max_workspace_size(ranks_per_node) */
         uint32_t timeout_ms;
+        void* peer_comm_buffer_ptrs_ping[MI355Q_MAX_RANKS_PER_NODE];
+        void* peer_comm_buffer_ptrs_pong[MI355Q_MAX_RANKS_PER_NODE];
     } mi355q_allreduce_params;
     /* AllReduceParams::deserialize(buffer, tpSize, tpRank, flag_value) (customAllReduceKernels.cu:398-425):
      * buffer_ptrs = HOST array [4 * tpSize]: ping buffers | pong buffers | barrier-in | barrier-out, one per rank */
@@ -512,6 +522,22 @@ extern "C"
     mi355q_status mi355q_ipc_get_handle(void* ptr, uint8_t handle[MI355Q_IPC_HANDLE_BYTES]);
     mi355q_status mi355q_ipc_open_handle(const uint8_t handle[MI355Q_IPC_HANDLE_BYTES], void** ptr);
     mi355q_status mi355q_ipc_close_handle(void* ptr);
+
+    /* ---- RCCL communicators for the RING strategy of "AllReduce" and for "AllGather" without a workspace table:
+     * getCommMap / initCommMap (plugins/common/plugin.cpp:44-87).  The reference creates a communicator per rank group
+     * in AllreducePlugin::initialize -- the group's first rank calls ncclGetUniqueId and ships the id over MPI, every
+     * rank calls ncclCommInitRank -- and its enqueue issues ncclAllReduce / ncclAllGather on it
+     * (allreducePlugin.cpp:181-185, allgatherPlugin.cpp:90-110).  Without MPI the id travels by the host's own means
+     * (torch.distributed in mi355q/ipc.py): get_unique_id on one rank, init_rank on every rank of the group
+     * (group_rank = this rank's position in the sorted group; the device that is current at the call is the rank's
+     * GPU; a group that already has a communicator is left alone, as :54).  librccl.so.1 is loaded at the first of
+     * these calls, not at library load.  comm_destroy = AllreducePlugin::terminate (:254-267). */
+#define MI355Q_COMM_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+    mi355q_status mi355q_comm_get_unique_id(uint8_t id[MI355Q_COMM_UNIQUE_ID_BYTES]);
+    mi355q_status mi355q_comm_init_rank(const int32_t* group, int32_t group_size,
+        const uint8_t id[MI355Q_COMM_UNIQUE_ID_BYTES], int32_t group_rank);
+    int32_t mi355q_comm_exists(const int32_t* group, int32_t group_size); /* 1 / 0, negative on error */
+    mi355q_status mi355q_comm_destroy(const int32_t* group, int32_t group_size);
 
 #ifdef __cplusplus
 }

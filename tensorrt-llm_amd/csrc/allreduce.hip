@@ -14,10 +14,18 @@
 //     (sc0 sc1: system scope) into fine-grained memory, every storing wave drains `vmcnt(0)`, workgroup barrier, ONE
 //     lane per peer stores the flag (system-scope atomic store); the consumer polls its own flag words with relaxed
 //     system-scope loads and reads the payload with sc0 sc1 loads (peers wrote it behind this GPU's L2).
-//   * flags carry the call counter and are compared with `>=` (a peer may already be one call ahead and have
-//     overwritten the word); the payload alternates between the ping and pong buffers so that a rank one call ahead
-//     never overwrites bytes a slower rank still reads.
-//   * every wait is bounded by the wall clock (s_memrealtime; params.timeout_ms, default 2 s).  On expiry the kernel
+//   * the flag value and the ping / pong parity of a call come from a DEVICE-RESIDENT epoch, not from the host: the
+//     reference bakes `counter` into every plugin at build time (allreducePlugin.cpp:194, functional.py gen_id()), so an
+//     engine or a hipGraph replays the same counters 1..N on every pass -- with the wrap-safe `>=` wait below, call #1 of
+//     the second pass would fall through on the N left by the first.  Each rank keeps a word behind the flags of its
+//     own barrier-in array that counts the collectives launched on it; every workgroup reads it at its start, counts
+//     itself on an arrival word beside it (wrapping increment), and the last one to count stores epoch + 1 for the
+//     next launch on the stream.  All ranks issue the same sequence of collectives, so their epochs agree; flags
+//     carry epoch + 1 and are compared with `>=` (a peer may already be one call ahead and have overwritten the
+//     word); the payload alternates between the ping and pong buffers by the epoch's parity so that a rank one call
+//     ahead never overwrites bytes a slower rank still reads.  AllGather shares the same words and needs no counter.
+//     params.barrier_flag (the host counter) is carried for the reference's serialized form and otherwise unused.
+//   * every wait is bounded by the wall clock (s_memrealtime; params.timeout_ms, default 30 s).  On expiry the kernel
 //     sets *timeout_flag (host-visible, mi355q_allreduce_alloc_timeout_flag) and POISONS its output with NaN instead
 //     of summing stale bytes; the plugin refuses further work once the flag is set.
 // Summation order (bit-exact with the reference, checked against oracle.custom_all_reduce): one-shot adds the ranks'
@@ -37,6 +45,10 @@ constexpr int AR_THREADS = 256;
 constexpr int AR_MAX_WGS = MI355Q_AR_MAX_WORKGROUPS;
 constexpr size_t AR_MIN_CHUNK = 4096; // bytes per workgroup before another workgroup is worth its flags
 constexpr int AR_SC_SYSTEM = 17;      // buffer aux bits: sc0 (1) | sc1 (16)
+// words behind the flags of a barrier array (mi355q_allreduce_barrier_bytes covers them): the rank's epoch and the
+// arrival word of the running launch, on separate 128-byte lines; only this rank's own kernels touch them
+constexpr size_t AR_STATE_OFF = (size_t) 2 * MI355Q_MAX_RANKS_PER_NODE * AR_MAX_WGS;
+constexpr size_t AR_STATE_WORDS = 64;
 
 typedef __attribute__((ext_vector_type(2))) _Float16 ar_f16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t ar_u32x4;
@@ -87,10 +99,10 @@ struct ArArgs
     size_t chunk_bytes; // per workgroup: of the message (one-shot) or of a slice (two-shot); a multiple of 16
     size_t slot_bytes;  // one-shot: stride of the ranks' slots in a comm buffer; two-shot: bytes of a slice
     int ranks, rank;
-    uint32_t flag;
     uint32_t* barrier_in[MI355Q_MAX_RANKS_PER_NODE];
     uint32_t* barrier_out[MI355Q_MAX_RANKS_PER_NODE];
-    uint8_t* comm[MI355Q_MAX_RANKS_PER_NODE];
+    uint8_t* ping[MI355Q_MAX_RANKS_PER_NODE]; // comm buffers of the calls with an even flag
+    uint8_t* pong[MI355Q_MAX_RANKS_PER_NODE]; // ... with an odd flag
     const uint8_t* in;
     uint8_t* out;
     uint32_t* timeout_flag;
@@ -126,18 +138,38 @@ __device__ __forceinline__ bool flag_wait(uint32_t* addr, uint32_t flag, uint64_
     }
 }
 
+// The start of every workgroup of a collective: the flag of this call = the rank's epoch + 1.  Lane 0 reads the epoch,
+// then (the load has returned) counts the workgroup on the arrival word; the workgroup whose count completes the
+// launch stores epoch + 1 -- every workgroup has read the old value by then, and the next launch on the stream starts
+// after this one has ended.  The wrapping increment leaves the arrival word at zero.
+__device__ __forceinline__ uint32_t take_flag(uint32_t* state, int* lds)
+{
+    if (threadIdx.x == 0)
+    {
+        const uint32_t e = __hip_atomic_load((ar_gu32*) state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds[1] = (int) (e + 1);
+        lds[0] = 0; // `failed`
+        const uint32_t seen = __builtin_amdgcn_atomic_inc32((ar_gu32*) (state + 32), gridDim.x - 1, __ATOMIC_RELAXED, "agent");
+        if (seen == gridDim.x - 1)
+            __hip_atomic_store((ar_gu32*) state, e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return (uint32_t) __builtin_amdgcn_readfirstlane(lds[1]);
+}
+
 // after a workgroup's stores into the peers: drain, barrier, one lane per peer raises this workgroup's flag of
 // `phase` there and waits for the peers' same flag here.  Returns false (block-uniform) if a peer never arrived.
 template <int RANKS>
-__device__ __forceinline__ bool publish_and_wait(const ArArgs& p, int phase, int w, int* failed_lds)
+__device__ __forceinline__ bool publish_and_wait(const ArArgs& p, uint32_t flag, int phase, int w, int* failed_lds)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // EVERY storing wave, before the barrier the signalling lanes pass
     __syncthreads();
     const int tid = threadIdx.x;
     if (tid < RANKS)
     {
-        flag_store(p.barrier_in[tid] + ((size_t) (phase * RANKS + p.rank) * AR_MAX_WGS + w), p.flag);
-        if (!flag_wait(p.barrier_in[p.rank] + ((size_t) (phase * RANKS + tid) * AR_MAX_WGS + w), p.flag, p.timeout_ticks))
+        flag_store(p.barrier_in[tid] + ((size_t) (phase * RANKS + p.rank) * AR_MAX_WGS + w), flag);
+        if (!flag_wait(p.barrier_in[p.rank] + ((size_t) (phase * RANKS + tid) * AR_MAX_WGS + w), flag, p.timeout_ticks))
         {
             if (p.timeout_flag)
                 __hip_atomic_store(p.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -153,18 +185,19 @@ __device__ __forceinline__ bool publish_and_wait(const ArArgs& p, int phase, int
 template <typename T, int RANKS>
 __global__ __launch_bounds__(AR_THREADS) void one_shot_push_kernel(ArArgs p)
 {
-    __shared__ int failed;
+    __shared__ int lds[2]; // failed | flag
     const int w = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0)
-        failed = 0;
+    const uint32_t flag = take_flag(p.barrier_in[p.rank] + AR_STATE_OFF, lds);
+    const bool odd = flag & 1;
+    uint8_t* const own = odd ? p.pong[p.rank] : p.ping[p.rank];
     const size_t begin = (size_t) w * p.chunk_bytes;
     const size_t end = min(begin + p.chunk_bytes, p.total_bytes);
     __amdgpu_buffer_rsrc_t dst[RANKS], src[RANKS];
 #pragma unroll
     for (int i = 0; i < RANKS; ++i)
     {
-        dst[i] = ar_rsrc(p.comm[i] + (size_t) p.rank * p.slot_bytes, p.total_bytes);                         // my slot, at rank i
-        src[i] = ar_rsrc(p.comm[p.rank] + (size_t) ((p.rank + i) % RANKS) * p.slot_bytes, p.total_bytes);   // order of the sum
+        dst[i] = ar_rsrc((odd ? p.pong[i] : p.ping[i]) + (size_t) p.rank * p.slot_bytes, p.total_bytes); // my slot, at rank i
+        src[i] = ar_rsrc(own + (size_t) ((p.rank + i) % RANKS) * p.slot_bytes, p.total_bytes);           // order of the sum
     }
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_push_kernel(ArArgs p)
         for (int i = 0; i < RANKS; ++i)
             __builtin_amdgcn_raw_buffer_store_b128(v, dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
     }
-    const bool ok = publish_and_wait<RANKS>(p, 0, w, &failed);
+    const bool ok = publish_and_wait<RANKS>(p, flag, 0, w, lds);
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
         ar_u32x4 vals[RANKS];
@@ -195,10 +228,11 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_push_kernel(ArArgs p)
 template <typename T, int RANKS>
 __global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
 {
-    __shared__ int failed;
+    __shared__ int lds[2]; // failed | flag
     const int w = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0)
-        failed = 0;
+    const uint32_t flag = take_flag(p.barrier_in[p.rank] + AR_STATE_OFF, lds);
+    const bool odd = flag & 1;
+    uint8_t* const own = odd ? p.pong[p.rank] : p.ping[p.rank];
     const size_t slice = p.slot_bytes;
     const size_t begin = (size_t) w * p.chunk_bytes;
     const size_t end = min(begin + p.chunk_bytes, slice);
@@ -206,11 +240,12 @@ __global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
 #pragma unroll
     for (int i = 0; i < RANKS; ++i)
     {
-        scatter_dst[i] = ar_rsrc(p.comm[i] + (size_t) p.rank * slice, slice);
-        scatter_src[i] = ar_rsrc(p.comm[p.rank] + (size_t) ((p.rank + i) % RANKS) * slice, slice);
-        gather_dst[i] = ar_rsrc(p.comm[i] + (size_t) (RANKS + p.rank) * slice, slice);
+        uint8_t* const peer = odd ? p.pong[i] : p.ping[i];
+        scatter_dst[i] = ar_rsrc(peer + (size_t) p.rank * slice, slice);
+        scatter_src[i] = ar_rsrc(own + (size_t) ((p.rank + i) % RANKS) * slice, slice);
+        gather_dst[i] = ar_rsrc(peer + (size_t) (RANKS + p.rank) * slice, slice);
     }
-    const __amdgpu_buffer_rsrc_t gather_src = ar_rsrc(p.comm[p.rank] + (size_t) RANKS * slice, (size_t) RANKS * slice);
+    const __amdgpu_buffer_rsrc_t gather_src = ar_rsrc(own + (size_t) RANKS * slice, (size_t) RANKS * slice);
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
 #pragma unroll
@@ -220,7 +255,7 @@ __global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
             __builtin_amdgcn_raw_buffer_store_b128(v, scatter_dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
         }
     }
-    bool ok = publish_and_wait<RANKS>(p, 0, w, &failed);
+    bool ok = publish_and_wait<RANKS>(p, flag, 0, w, lds);
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
         ar_u32x4 vals[RANKS];
@@ -237,7 +272,7 @@ __global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
         for (int i = 0; i < RANKS; ++i)
             __builtin_amdgcn_raw_buffer_store_b128(sum, gather_dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
     }
-    ok = publish_and_wait<RANKS>(p, 1, w, &failed) && ok;
+    ok = publish_and_wait<RANKS>(p, flag, 1, w, lds) && ok;
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
 #pragma unroll
@@ -255,17 +290,17 @@ __global__ __launch_bounds__(AR_THREADS) void two_shot_push_kernel(ArArgs p)
 template <int RANKS>
 __global__ __launch_bounds__(AR_THREADS) void all_gather_push_kernel(ArArgs p)
 {
-    __shared__ int failed;
+    __shared__ int lds[2]; // failed | flag
     const int w = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0)
-        failed = 0;
+    const uint32_t flag = take_flag(p.barrier_in[p.rank] + AR_STATE_OFF, lds);
+    const bool odd = flag & 1;
     const size_t begin = (size_t) w * p.chunk_bytes;
     const size_t end = min(begin + p.chunk_bytes, p.total_bytes); // total_bytes = one rank's shard
     __amdgpu_buffer_rsrc_t dst[RANKS];
 #pragma unroll
     for (int i = 0; i < RANKS; ++i)
-        dst[i] = ar_rsrc(p.comm[i] + (size_t) p.rank * p.slot_bytes, p.total_bytes);
-    const __amdgpu_buffer_rsrc_t src = ar_rsrc(p.comm[p.rank], (size_t) RANKS * p.slot_bytes);
+        dst[i] = ar_rsrc((odd ? p.pong[i] : p.ping[i]) + (size_t) p.rank * p.slot_bytes, p.total_bytes);
+    const __amdgpu_buffer_rsrc_t src = ar_rsrc(odd ? p.pong[p.rank] : p.ping[p.rank], (size_t) RANKS * p.slot_bytes);
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
         const ar_u32x4 v = *reinterpret_cast<const ar_u32x4*>(p.in + off);
@@ -273,7 +308,7 @@ __global__ __launch_bounds__(AR_THREADS) void all_gather_push_kernel(ArArgs p)
         for (int i = 0; i < RANKS; ++i)
             __builtin_amdgcn_raw_buffer_store_b128(v, dst[i], (uint32_t) off, 0, AR_SC_SYSTEM);
     }
-    const bool ok = publish_and_wait<RANKS>(p, 0, w, &failed);
+    const bool ok = publish_and_wait<RANKS>(p, flag, 0, w, lds);
     for (size_t off = begin + (size_t) tid * 16; off < end; off += (size_t) AR_THREADS * 16)
     {
         ar_u32x4 vals[RANKS];
@@ -288,17 +323,27 @@ __global__ __launch_bounds__(AR_THREADS) void all_gather_push_kernel(ArArgs p)
 }
 
 // invokeMultiGpuBarrier (customAllReduceKernels.cu:391-394): every rank has reached this point of its stream
+// (one workgroup; its flag is the epoch word behind the barrier-out flags, bumped like the collectives')
 __global__ void multi_gpu_barrier_kernel(ArArgs p)
 {
+    __shared__ int lds[2];
     const int tid = threadIdx.x;
+    const uint32_t flag = take_flag(p.barrier_out[p.rank] + AR_STATE_OFF, lds);
     if (tid < p.ranks)
     {
-        flag_store(p.barrier_out[tid] + p.rank, p.flag);
-        if (!flag_wait(p.barrier_out[p.rank] + tid, p.flag, p.timeout_ticks) && p.timeout_flag)
+        flag_store(p.barrier_out[tid] + p.rank, flag);
+        if (!flag_wait(p.barrier_out[p.rank] + tid, flag, p.timeout_ticks) && p.timeout_flag)
             __hip_atomic_store(p.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
+} // namespace
+size_t allreduce_barrier_bytes()
+{
+    return (AR_STATE_OFF + AR_STATE_WORDS) * sizeof(uint32_t);
+}
+namespace
+{
 size_t div_up(size_t a, size_t b)
 {
     return (a + b - 1) / b;
@@ -314,7 +359,10 @@ void check_params(const mi355q_allreduce_params& q)
     MQ_CHECK(q.ranks_per_node >= 2 && q.ranks_per_node <= MI355Q_MAX_RANKS_PER_NODE, "ranks_per_node %zu", q.ranks_per_node);
     MQ_CHECK(q.local_rank < q.ranks_per_node && q.rank < q.ranks_per_node, "rank %zu / local_rank %zu", q.rank, q.local_rank);
     for (size_t i = 0; i < q.ranks_per_node; ++i)
-        MQ_CHECK(q.peer_barrier_ptrs_in[i] && q.peer_barrier_ptrs_out[i] && q.peer_comm_buffer_ptrs[i], "null peer pointer %zu", i);
+        MQ_CHECK(q.peer_barrier_ptrs_in[i] && q.peer_barrier_ptrs_out[i] && q.peer_comm_buffer_ptrs_ping[i]
+                && q.peer_comm_buffer_ptrs_pong[i],
+            "null peer pointer %zu (the kernels pick ping / pong themselves: fill the params with "
+            "mi355q_allreduce_params_deserialize)", i);
 }
 
 ArArgs to_args(const mi355q_allreduce_params& q)
@@ -322,16 +370,16 @@ ArArgs to_args(const mi355q_allreduce_params& q)
     ArArgs a{};
     a.ranks = (int) q.ranks_per_node;
     a.rank = (int) q.local_rank;
-    a.flag = q.barrier_flag;
     for (size_t i = 0; i < q.ranks_per_node; ++i)
     {
         a.barrier_in[i] = q.peer_barrier_ptrs_in[i];
         a.barrier_out[i] = q.peer_barrier_ptrs_out[i];
-        a.comm[i] = static_cast<uint8_t*>(q.peer_comm_buffer_ptrs[i]);
+        a.ping[i] = static_cast<uint8_t*>(q.peer_comm_buffer_ptrs_ping[i]);
+        a.pong[i] = static_cast<uint8_t*>(q.peer_comm_buffer_ptrs_pong[i]);
     }
     a.out = static_cast<uint8_t*>(q.local_output_buffer_ptr);
     a.timeout_flag = q.timeout_flag;
-    a.timeout_ticks = (uint64_t) (q.timeout_ms ? q.timeout_ms : 2000u) * 100000ull; // 100 MHz
+    a.timeout_ticks = (uint64_t) (q.timeout_ms ? q.timeout_ms : 30000u) * 100000ull; // 100 MHz
     return a;
 }
 
@@ -403,11 +451,14 @@ void allreduce_params_deserialize(
     MQ_CHECK(buffer_ptrs, "null workspace");
     MQ_CHECK(tpSize >= 2 && tpSize <= MI355Q_MAX_RANKS_PER_NODE && tpRank < tpSize, "tpSize %zu tpRank %zu", tpSize, tpRank);
     out = mi355q_allreduce_params{};
-    // even calls use the ping buffers, odd ones the pong buffers (header comment)
+    // the reference's field: even flags name the ping buffers, odd ones the pong buffers.  The kernels here take both
+    // sets and choose by their device-resident epoch (header comment), not by flag_value.
     const size_t buffer_offset = (flag_value % 2 == 0) ? 0 : tpSize;
     for (size_t i = 0; i < tpSize; ++i)
     {
         out.peer_comm_buffer_ptrs[i] = const_cast<void*>(buffer_ptrs[buffer_offset + i]);
+        out.peer_comm_buffer_ptrs_ping[i] = const_cast<void*>(buffer_ptrs[i]);
+        out.peer_comm_buffer_ptrs_pong[i] = const_cast<void*>(buffer_ptrs[tpSize + i]);
         out.peer_barrier_ptrs_in[i] = static_cast<uint32_t*>(const_cast<void*>(buffer_ptrs[2 * tpSize + i]));
         out.peer_barrier_ptrs_out[i] = static_cast<uint32_t*>(const_cast<void*>(buffer_ptrs[3 * tpSize + i]));
     }

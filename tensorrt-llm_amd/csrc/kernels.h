@@ -91,6 +91,7 @@ void allreduce_params_deserialize(
 void custom_all_reduce(mi355q_allreduce_params& params, void* data, size_t elts, int dtype, int strat, hipStream_t stream);
 void custom_all_gather(mi355q_allreduce_params& params, const void* in, void* out, size_t bytes_per_rank, hipStream_t stream);
 void multi_gpu_barrier_launch(const mi355q_allreduce_params& params, hipStream_t stream);
+size_t allreduce_barrier_bytes();
 void allreduce_alloc_timeout_flag(uint32_t** flag);
 void allreduce_free_timeout_flag(uint32_t* flag);
 void ipc_alloc(size_t bytes, void** ptr);
@@ -98,6 +99,13 @@ void ipc_free(void* ptr);
 void ipc_get_handle(void* ptr, uint8_t* handle);
 void ipc_open_handle(const uint8_t* handle, void** ptr);
 void ipc_close_handle(void* ptr);
+// rccl_comm.cpp
+void comm_get_unique_id(uint8_t* id);
+void comm_init_rank(const int32_t* group, int n, const uint8_t* id, int group_rank);
+bool comm_exists(const int32_t* group, int n);
+void comm_destroy(const int32_t* group, int n);
+void comm_all_reduce(const int32_t* group, int n, const void* in, void* out, size_t count, int dtype, hipStream_t stream);
+void comm_all_gather(const int32_t* group, int n, const void* in, void* out, size_t count, int dtype, hipStream_t stream);
 
 // decode_attn.hip
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q);

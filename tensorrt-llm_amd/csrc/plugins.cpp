@@ -702,10 +702,11 @@ struct AllReducePlugin : PluginBase
         const int64_t size = dims_prod(inDesc[0].dims, 0, inDesc[0].dims.nbDims);
         const size_t sizePerElem = dtype_size(mType);
         int runtimeStrategy = mStrategy;
-        if (runtimeStrategy == MI355Q_AR_RING)
-            MQ_UNSUPPORTED(
-                "AllReduce: the RING strategy is RCCL's all-reduce, issued by the host side (torch.distributed, "
-                "mi355q/tp.py all_reduce_sum); this plugin runs ONESHOT / TWOSHOT");
+        if (runtimeStrategy == MI355Q_AR_RING) // :181-185
+        {
+            comm_all_reduce(mGroup.data(), (int) mGroup.size(), inputs[0], outputs[0], (size_t) size, mType, stream);
+            return;
+        }
         // the workspace table: 4 pointers per rank (NUM_POINTERS_PER_RANK), optionally followed by two more entries this
         // library's CustomAllReduceHelper appends: the byte size of a comm buffer and the host-visible timeout word
         const int len = inDesc[1].dims.d[0];
@@ -735,9 +736,11 @@ struct AllReducePlugin : PluginBase
         }
         if (mStrategy == MI355Q_AR_AUTO) // selectImplementation, :111-139, for the real buffer size
             runtimeStrategy = mi355q_allreduce_select_implementation(size * sizePerElem, nRanks, params.comm_buffer_bytes);
-        if (runtimeStrategy == MI355Q_AR_RING)
-            MQ_UNSUPPORTED("AllReduce: a message of %lld bytes does not fit the %zu-byte comm buffers: RING (RCCL) is the "
-                           "host side's call (mi355q/tp.py all_reduce_sum)", (long long) (size * sizePerElem), params.comm_buffer_bytes);
+        if (runtimeStrategy == MI355Q_AR_RING) // AUTO beyond the comm buffers (:115-118)
+        {
+            comm_all_reduce(mGroup.data(), (int) mGroup.size(), inputs[0], outputs[0], (size_t) size, mType, stream);
+            return;
+        }
         custom_all_reduce(params, outputs[0], size, mType, runtimeStrategy, stream);
     }
     size_t serializationSize() const override // :268-284
@@ -756,21 +759,25 @@ struct AllReducePlugin : PluginBase
 
 // ===================================================================== AllGather
 // plugins/ncclPlugin/allgatherPlugin.{h,cpp}: input 0 the local tensor (type_id); output = the group's tensors back to
-// back along dim 0 (:66-72, :96-110).  The reference calls ncclAllGather on an MPI-bootstrapped communicator; here the
-// gather runs on the custom all-reduce's IPC buffers, so the plugin takes the same second input as AllReduce (the HOST
-// int64 workspace table); messages that do not fit go through the host side's RCCL call (mi355q/tp.py).
+// back along dim 0 (:66-72, :96-110).  The reference's form -- one input, ncclAllGather on the group's communicator --
+// is what a created-without-"strategy" or deserialized instance runs (RCCL through rccl_comm.cpp).  An instance created
+// with the extra field strategy = ONESHOT takes the AllReduce plugin's HOST int64 workspace table as a second input and
+// gathers through the push kernel on those IPC buffers (the flag value comes from the buffers' device-resident epoch:
+// no counter is needed, so there is nothing a reference-built network would have to supply).  The serialized form is
+// the reference's (type, group): it does not carry the strategy, a deserialized instance is the RCCL form.
 struct AllGatherPlugin : PluginBase
 {
     std::vector<int32_t> mGroup;
     int32_t mType;
-    int32_t mCounter, mRank;
-    AllGatherPlugin(std::vector<int32_t> group, int type, int counter, int rank)
+    int32_t mStrategy, mRank;
+    AllGatherPlugin(std::vector<int32_t> group, int type, int strategy, int rank)
         : mGroup(std::move(group))
         , mType(type)
-        , mCounter(counter)
+        , mStrategy(strategy)
         , mRank(rank)
     {
         MQ_CHECK(dtype_size(mType) > 0, "AllGather: data type %d", mType);
+        MQ_CHECK(mStrategy == MI355Q_AR_RING || mStrategy == MI355Q_AR_ONESHOT, "AllGather: strategy %d (RING or ONESHOT)", mStrategy);
     }
     const char* type() const override
     {
@@ -788,7 +795,7 @@ struct AllGatherPlugin : PluginBase
     }
     bool supportsFormatCombination(int pos, const mi355q_tensor_desc* io, int nbIn, int) const override // :74-79
     {
-        if (pos == 1 && nbIn == 2)
+        if (mStrategy != MI355Q_AR_RING && pos == 1 && nbIn == 2)
             return io[pos].type == MI355Q_INT64 && io[pos].format == 0;
         return io[pos].type == mType && io[pos].format == 0;
     }
@@ -801,8 +808,13 @@ struct AllGatherPlugin : PluginBase
         void* const* outputs, void*, hipStream_t stream) override // :90-110
     {
         const int64_t size = dims_prod(inDesc[0].dims, 0, inDesc[0].dims.nbDims);
-        const int len = inDesc[1].dims.d[0];
         const int nRanks = (int) mGroup.size();
+        if (mStrategy == MI355Q_AR_RING) // ncclAllGather(inputs[0], outputs[0], size, dtype, comm, stream), as bytes
+        {
+            comm_all_gather(mGroup.data(), nRanks, inputs[0], outputs[0], (size_t) size * dtype_size(mType), MI355Q_INT8, stream);
+            return;
+        }
+        const int len = inDesc[1].dims.d[0];
         MQ_CHECK(nRanks >= 2 && (len == 4 * nRanks || len == 4 * nRanks + 2), "all_reduce_workspace length %d for %d ranks",
             len, nRanks);
         const int64_t* table = static_cast<const int64_t*>(inputs[1]);
@@ -815,7 +827,7 @@ struct AllGatherPlugin : PluginBase
         }
         myRank %= nRanks;
         mi355q_allreduce_params params;
-        allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, mCounter);
+        allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, 0);
         params.comm_buffer_bytes = mi355q_allreduce_max_workspace_size(nRanks);
         if (len == 4 * nRanks + 2)
         {
@@ -825,7 +837,13 @@ struct AllGatherPlugin : PluginBase
                 MQ_CHECK(*static_cast<volatile uint32_t*>(params.timeout_flag) == 0,
                     "AllGather: an earlier collective timed out waiting for a peer rank");
         }
-        custom_all_gather(params, inputs[0], outputs[0], (size_t) size * dtype_size(mType), stream);
+        const size_t bytes = (size_t) size * dtype_size(mType);
+        if (bytes % 16 != 0 || (size_t) nRanks * ((bytes + 255) / 256 * 256) > params.comm_buffer_bytes)
+        {
+            comm_all_gather(mGroup.data(), nRanks, inputs[0], outputs[0], bytes, MI355Q_INT8, stream); // does not fit: RCCL
+            return;
+        }
+        custom_all_gather(params, inputs[0], outputs[0], bytes, stream);
     }
     size_t serializationSize() const override // :147-150: type, then the group
     {
@@ -1564,7 +1582,7 @@ PluginBase* create_plugin(const char* name, const FieldReader& r)
         const mi355q_plugin_field* g = r.find("group");
         MQ_CHECK(g && g->type == MI355Q_FIELD_INT32 && g->length > 0, "AllGather: field 'group' (int32 list) is missing");
         const int32_t* gi = static_cast<const int32_t*>(g->data);
-        return new AllGatherPlugin(std::vector<int32_t>(gi, gi + g->length), r.req_int("type_id"), r.opt_int("counter", 0),
+        return new AllGatherPlugin(std::vector<int32_t>(gi, gi + g->length), r.req_int("type_id"), r.opt_int("strategy", MI355Q_AR_RING),
             r.opt_int("rank", -1));
     }
     if (n == "AllReduce") // createPlugin, allreducePlugin.cpp:306-350
@@ -1673,7 +1691,7 @@ PluginBase* deserialize_plugin(const char* name, const void* data, size_t length
         std::vector<int32_t> group((length - 4) / 4);
         for (auto& g : group)
             read(d, g);
-        out = new AllGatherPlugin(group, t, 0, -1);
+        out = new AllGatherPlugin(group, t, MI355Q_AR_RING, -1);
     }
     else if (n == "AllReduce") // allreducePlugin.cpp:42-62: type, strategy, counter, then the group to the end
     {
@@ -2180,7 +2198,7 @@ extern "C"
 
     size_t mi355q_allreduce_barrier_bytes(void)
     {
-        return (size_t) 2 * MI355Q_MAX_RANKS_PER_NODE * MI355Q_AR_MAX_WORKGROUPS * sizeof(uint32_t);
+        return allreduce_barrier_bytes();
     }
 
     mi355q_status mi355q_allreduce_alloc_timeout_flag(uint32_t** flag)
@@ -2232,6 +2250,26 @@ extern "C"
     mi355q_status mi355q_ipc_close_handle(void* ptr)
     {
         return guarded([&] { ipc_close_handle(ptr); });
+    }
+
+    mi355q_status mi355q_comm_get_unique_id(uint8_t id[MI355Q_COMM_UNIQUE_ID_BYTES])
+    {
+        return guarded([&] { comm_get_unique_id(id); });
+    }
+    mi355q_status mi355q_comm_init_rank(
+        const int32_t* group, int32_t group_size, const uint8_t id[MI355Q_COMM_UNIQUE_ID_BYTES], int32_t group_rank)
+    {
+        return guarded([&] { comm_init_rank(group, group_size, id, group_rank); });
+    }
+    int32_t mi355q_comm_exists(const int32_t* group, int32_t group_size)
+    {
+        int32_t res = 0;
+        const mi355q_status st = guarded([&] { res = comm_exists(group, group_size) ? 1 : 0; });
+        return st == MI355Q_OK ? res : (int32_t) st;
+    }
+    mi355q_status mi355q_comm_destroy(const int32_t* group, int32_t group_size)
+    {
+        return guarded([&] { comm_destroy(group, group_size); });
     }
 
     // AllreducePlugin::selectImplementation, plugins/ncclPlugin/allreducePlugin.cpp:111-139

@@ -129,7 +129,7 @@ class ContextAttentionParams(C.Structure):
     ]
 
 
-MAX_RANKS_PER_NODE, IPC_HANDLE_BYTES = 8, 64
+MAX_RANKS_PER_NODE, IPC_HANDLE_BYTES, COMM_UNIQUE_ID_BYTES = 8, 64, 128
 AR_RING, AR_ONESHOT, AR_TWOSHOT, AR_AUTO = range(4)
 
 
@@ -143,6 +143,8 @@ class AllReduceParams(C.Structure):
         ("peer_comm_buffer_ptrs", C.c_void_p * MAX_RANKS_PER_NODE),
         ("local_output_buffer_ptr", C.c_void_p), ("timeout_flag", C.c_void_p),
         ("local_input_buffer_ptr", C.c_void_p), ("comm_buffer_bytes", C.c_size_t), ("timeout_ms", C.c_uint32),
+        ("peer_comm_buffer_ptrs_ping", C.c_void_p * MAX_RANKS_PER_NODE),
+        ("peer_comm_buffer_ptrs_pong", C.c_void_p * MAX_RANKS_PER_NODE),
     ]
 
 
@@ -223,6 +225,10 @@ SYMBOLS = {
     "mi355q_ipc_get_handle": (_i32, [_vp, _vp]),
     "mi355q_ipc_open_handle": (_i32, [_vp, _PP]),
     "mi355q_ipc_close_handle": (_i32, [_vp]),
+    "mi355q_comm_get_unique_id": (_i32, [_vp]),
+    "mi355q_comm_init_rank": (_i32, [C.POINTER(_i32), _i32, _vp, _i32]),
+    "mi355q_comm_exists": (_i32, [C.POINTER(_i32), _i32]),
+    "mi355q_comm_destroy": (_i32, [C.POINTER(_i32), _i32]),
 }
 
 

@@ -49,6 +49,9 @@ class IpcMemory:
         if not self._open:
             return
         self._open = False
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()          # no kernel of this rank still polls or writes these buffers ...
+        dist.barrier(group=self.group)        # ... and none of a peer's either
         for r, ptr in enumerate(self.peer_ptrs):
             if r != self.rank:
                 L.lib().mi355q_ipc_close_handle(ptr)
@@ -56,9 +59,37 @@ class IpcMemory:
         L.lib().mi355q_ipc_free(self.local_ptr)
 
 
+def init_comm(group=None, ranks=None):
+    """initCommMap (plugins/common/plugin.cpp:50-87) without MPI: the group's first rank draws the RCCL unique id, it
+    travels through torch.distributed, every rank calls mi355q_comm_init_rank with the GPU that is current.  After this
+    the AllReduce plugin's RING strategy and the one-input AllGather plugin run inside the library.  `ranks`: the
+    group's global ranks as the plugins' `group` field names them (default 0 .. world-1)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ranks = list(range(world)) if ranks is None else sorted(ranks)
+    arr = (C.c_int32 * world)(*ranks)
+    if L.lib().mi355q_comm_exists(arr, world) == 1:
+        return
+    uid = (C.c_uint8 * L.COMM_UNIQUE_ID_BYTES)()
+    if rank == 0:
+        L.check(L.lib().mi355q_comm_get_unique_id(uid))
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    uid = (C.c_uint8 * L.COMM_UNIQUE_ID_BYTES).from_buffer_copy(box[0])
+    L.check(L.lib().mi355q_comm_init_rank(arr, world, uid, rank))
+
+
+def destroy_comm(group=None, ranks=None):
+    world = dist.get_world_size(group)
+    ranks = list(range(world)) if ranks is None else sorted(ranks)
+    L.check(L.lib().mi355q_comm_destroy((C.c_int32 * world)(*ranks), world))
+
+
 class CustomAllReduceHelper:
     """allocate_workspace (plugin.py:386-403): ping / pong comm buffers + barrier-in / barrier-out flag arrays; the
-    workspace tensor is the HOST int64 [4 * tp_size] pointer table the AllReduce plugin takes as its second input."""
+    workspace tensor is the HOST int64 [4 * tp_size] pointer table the AllReduce plugin takes as its second input.
+    The kernels number the collectives themselves (a device-resident epoch in the barrier arrays), so the `counter`
+    plugin field below only mirrors the reference's gen_id() and may repeat (engine / hipGraph replay)."""
 
     POINTERS_PER_RANK = 4
 
@@ -84,11 +115,19 @@ class CustomAllReduceHelper:
         # the reference's table (4 pointers per rank) + the comm-buffer byte size + the timeout word
         self.workspace = torch.tensor(ptrs + [size, self._timeout_flag], dtype=torch.int64, device="cpu")
         self.counter = 0
+        self._ranks = (C.c_int32 * self.world)(*range(self.world))
+
+    def has_rccl(self):
+        """True once init_comm() has given this group a communicator inside the library."""
+        return L.lib().mi355q_comm_exists(self._ranks, self.world) == 1
 
     def timed_out(self):
         return C.cast(self._timeout_flag, C.POINTER(C.c_uint32))[0] != 0
 
     def close(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()   # a collective still in flight may write the host-mapped timeout word
+        dist.barrier(group=self.group)
         timed_out = self.timed_out()
         for b in self.buffers:
             b.close()
@@ -108,19 +147,32 @@ class CustomAllReduceHelper:
         return p
 
     def allreduce(self, tensor, strategy=L.AR_AUTO, out=None, direct=False):
-        """functional.py `allreduce(tensor, group, workspace, strategy)`: RING -> RCCL (torch.distributed), else the
-        AllReduce plugin (one-shot / two-shot; `direct`: the launcher below the plugin, which also takes `timeout_ms`).
-        Every call advances the barrier flag / ping-pong counter."""
+        """functional.py `allreduce(tensor, group, workspace, strategy)` through the AllReduce plugin: one-shot /
+        two-shot push kernels, RING (or AUTO / an explicit strategy beyond the comm buffers) = ncclAllReduce inside the
+        plugin once init_comm() has run; `direct`: the launcher below the plugin, which also takes `timeout_ms`.
+        Without a communicator in the library (ranks sharing one GPU in the tests, a gloo rehearsal on the CPU -- RCCL
+        takes one rank per GPU) the RING leg goes through torch.distributed instead."""
         nbytes = tensor.numel() * tensor.element_size()
         strat = strategy
         if strat == L.AR_AUTO:
             strat = L.lib().mi355q_allreduce_select_implementation(nbytes, self.world, self.size)
+        elif strat == L.AR_ONESHOT and self.world * ((nbytes + 255) // 256 * 256) > self.size:
+            strat = L.AR_RING          # an explicit strategy whose message does not fit the comm buffers
+        elif strat == L.AR_TWOSHOT and 2 * nbytes > self.size:
+            strat = L.AR_RING
+        tensor = tensor.contiguous()
         if strat == L.AR_RING:
-            out = tensor.clone() if out is None else out.copy_(tensor)
-            dist.all_reduce(out, group=self.group)
+            if not (tensor.is_cuda and self.has_rccl()):
+                out = tensor.clone() if out is None else out.copy_(tensor)
+                dist.all_reduce(out, group=self.group)
+                return out
+            out = torch.empty_like(tensor) if out is None else out
+            plg = Plugin("AllReduce", [("group", list(range(self.world)), L.FIELD_INT32),
+                                       ("type_id", torch_dtype_to_trt(tensor.dtype), L.FIELD_INT32),
+                                       ("strategy", L.AR_RING, L.FIELD_INT8), ("counter", 0, L.FIELD_INT32)])
+            plg.enqueue([tensor], [out])
             return out
         self.counter += 1
-        tensor = tensor.contiguous()
         out = torch.empty_like(tensor) if out is None else out
         if direct:
             if self.timed_out():
@@ -146,7 +198,12 @@ class CustomAllReduceHelper:
         out = torch.empty(shape, dtype=tensor.dtype, device=tensor.device) if out is None else out
         slot = (nbytes + 255) // 256 * 256
         if nbytes % 16 or slot * self.world > self.size:
-            dist.all_gather(list(out.chunk(self.world, dim=0)), tensor, group=self.group)
+            if tensor.is_cuda and self.has_rccl():   # the reference's form: one input, ncclAllGather inside the plugin
+                plg = Plugin("AllGather", [("group", list(range(self.world)), L.FIELD_INT32),
+                                           ("type_id", torch_dtype_to_trt(tensor.dtype), L.FIELD_INT32)])
+                plg.enqueue([tensor], [out])
+            else:
+                dist.all_gather(list(out.chunk(self.world, dim=0)), tensor, group=self.group)
             return out
         self.counter += 1
         if direct:
@@ -158,6 +215,6 @@ class CustomAllReduceHelper:
             return out
         plg = Plugin("AllGather", [("group", list(range(self.world)), L.FIELD_INT32),
                                    ("type_id", torch_dtype_to_trt(tensor.dtype), L.FIELD_INT32),
-                                   ("counter", self.counter, L.FIELD_INT32), ("rank", self.rank, L.FIELD_INT32)])
+                                   ("strategy", L.AR_ONESHOT, L.FIELD_INT8), ("rank", self.rank, L.FIELD_INT32)])
         plg.enqueue([tensor, self.workspace], [out])
         return out

@@ -16,6 +16,77 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _replay_cases(rank, world, dev, helper, oracle, L):
+    """An engine replays the SAME build-time counters on every pass (allreducePlugin.cpp:194, functional.py gen_id()):
+    plugins with counters 1..3, serialized and deserialized like an engine load, enqueued as one sequence twice with
+    fresh data; then the same sequence captured in a hipGraph and replayed.  The kernels' device-resident epoch keeps
+    the ranks synchronised whatever the counters say."""
+    from mi355q.plugin import Plugin, torch_dtype_to_trt
+    os.environ["RANK"] = str(rank)  # a deserialized plugin has no 'rank' field: the reference asks MPI, here $RANK
+    n = 8 * 8192
+    plugins = []
+    for c, strat in ((1, L.AR_ONESHOT), (2, L.AR_TWOSHOT), (3, L.AR_ONESHOT)):
+        made = Plugin("AllReduce", [("group", list(range(world)), L.FIELD_INT32),
+                                    ("type_id", torch_dtype_to_trt(torch.bfloat16), L.FIELD_INT32),
+                                    ("strategy", strat, L.FIELD_INT8), ("counter", c, L.FIELD_INT32)])
+        plugins.append((Plugin.deserialize("AllReduce", made.serialize()), "oneshot" if strat == L.AR_ONESHOT else "twoshot"))
+    gather = Plugin("AllGather", [("group", list(range(world)), L.FIELD_INT32), ("type_id", torch_dtype_to_trt(torch.bfloat16), L.FIELD_INT32),
+                                  ("strategy", L.AR_ONESHOT, L.FIELD_INT8), ("rank", rank, L.FIELD_INT32)])
+
+    def data(seed):
+        g = torch.Generator().manual_seed(seed)
+        return [[(torch.randn(n, generator=g) * 3).to(torch.bfloat16) for _ in range(world)] for _ in range(len(plugins))]
+
+    def verify(tag, ins, outs, gout):
+        for i, (_, sname) in enumerate(plugins):
+            ref = oracle.custom_all_reduce(ins[i], rank, sname)
+            if not torch.equal(outs[i].cpu().view(torch.uint8), ref.view(torch.uint8)):
+                return False, f"rank {rank} {tag} call {i} ({sname}): max diff {(outs[i].cpu().float() - ref.float()).abs().max().item()}"
+        if not torch.equal(gout.cpu().view(torch.uint8), torch.cat(ins[0]).view(torch.uint8)):
+            return False, f"rank {rank} {tag}: all-gather differs"
+        return True, ""
+
+    x = [torch.empty(n, dtype=torch.bfloat16, device=dev) for _ in plugins]
+    y = [torch.empty(n, dtype=torch.bfloat16, device=dev) for _ in plugins]
+    gy = torch.empty(n * world, dtype=torch.bfloat16, device=dev)
+
+    def sequence():
+        for i, (plg, _) in enumerate(plugins):
+            plg.enqueue([x[i], helper.workspace], [y[i]])
+        gather.enqueue([x[0], helper.workspace], [gy])
+
+    for p in range(2):  # the same plugin objects, pass after pass
+        ins = data(500 + p)
+        for i in range(len(plugins)):
+            x[i].copy_(ins[i][rank])
+        sequence()
+        torch.cuda.synchronize()
+        ok, msg = verify(f"pass {p}", ins, y, gy)
+        if not ok:
+            return ok, msg
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    ins = data(600)
+    for i in range(len(plugins)):
+        x[i].copy_(ins[i][rank])
+    torch.cuda.synchronize()
+    dist.barrier()
+    with torch.cuda.graph(graph, stream=side):
+        sequence()
+    for p in range(3):
+        ins = data(601 + p)
+        for i in range(len(plugins)):
+            x[i].copy_(ins[i][rank])
+        for t in y:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ok, msg = verify(f"graph replay {p}", ins, y, gy)
+        if not ok:
+            return ok, msg
+    return True, ""
+
+
 def _worker(rank, world, port, results):
     sys.path.insert(0, os.path.join(HERE, ".."))
     sys.path.insert(0, os.path.join(HERE, "..", "tensorrt-llm_amd"))
@@ -29,13 +100,19 @@ def _worker(rank, world, port, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok, msg = True, ""
     try:
-        helper = CustomAllReduceHelper(size=8 << 20)
+        helper = CustomAllReduceHelper(size=8 << 20, timeout_ms=10000)  # the direct launcher's bound (the plugin's: 30 s)
+        say = (lambda m: print(f"[allreduce world {world}] {m}", flush=True)) if rank == 0 else (lambda m: None)
         # the last two: 1 MiB (256 workgroups of 4 KiB, the cfg4 M = 64 message) and 2 MiB per rank
+        # incl. the cfg4 messages [M, 8192] bf16 for M = 1, 8, 64 (16 KB, 128 KB, 1 MB)
         cases = [(torch.float16, 8 * 64), (torch.float16, 8 * 1024 * 3), (torch.bfloat16, 8192 * 4),
                  (torch.float32, 4 * 1024 * 5), (torch.float16, 8 * world * 999), (torch.bfloat16, 64 * world),
-                 (torch.bfloat16, 64 * 8192), (torch.float16, 1 << 20)]
+                 (torch.bfloat16, 8192), (torch.bfloat16, 8 * 8192), (torch.bfloat16, 64 * 8192), (torch.float16, 1 << 20)]
         for strat, sname in ((L.AR_ONESHOT, "oneshot"), (L.AR_TWOSHOT, "twoshot")):
             for ci, (dtype, n) in enumerate(cases):
+                nbytes = n * dtype.itemsize
+                if (world * nbytes if strat == L.AR_ONESHOT else 2 * nbytes) > helper.size:
+                    continue  # beyond the comm buffers an explicit strategy goes to RING: another summation order
+                say(f"{sname} case {ci}")
                 g = torch.Generator().manual_seed(1234 + n)
                 inputs = [(torch.randn(n, generator=g) * 3).to(dtype) for _ in range(world)]  # every rank builds all
                 x = inputs[rank].to(dev)
@@ -81,6 +158,10 @@ def _worker(rank, world, port, results):
                 y = helper.allgather(big)
                 ok = y.shape[0] == big.shape[0] * world
                 msg = "" if ok else f"rank {rank} allgather fallback shape {tuple(y.shape)}"
+        if ok:
+            say("replay")
+            ok, msg = _replay_cases(rank, world, dev, helper, oracle, L)
+        say(f"done ok={ok} {msg}")
         dist.barrier()
         helper.close()
         if ok and world == 2:
@@ -119,7 +200,7 @@ def _worker(rank, world, port, results):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_custom_allreduce_multi_process_single_gpu(cuda, world):
     ctx = mp.get_context("spawn")
     results = ctx.Queue()
@@ -129,9 +210,54 @@ def test_custom_allreduce_multi_process_single_gpu(cuda, world):
         p.start()
     got = []
     for _ in range(world):
-        got.append(results.get(timeout=100))
+        got.append(results.get(timeout=240))
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
     for rank, ok, msg in sorted(got):
         assert ok, msg
+
+
+def test_ring_strategy_runs_rccl_inside_the_plugin(cuda):
+    """RING = ncclAllReduce issued by AllreducePlugin::enqueue itself (allreducePlugin.cpp:181-185) on the communicator
+    of initCommMap (plugins/common/plugin.cpp:50-87); the reference's one-input AllGather likewise (allgatherPlugin.cpp:
+    90-110).  RCCL takes one rank per GPU and the box has one GPU, so the group here is {0}: this runs the whole C path
+    (librccl loaded on demand, unique id, ncclCommInitRank, the plugin's dispatch, the collective on torch's stream) --
+    the cross-GPU run is the TP leg of `bench.py --gpus N`."""
+    import ctypes as C
+    from mi355q import _lib as L
+    from mi355q.plugin import Plugin, torch_dtype_to_trt
+    grp = (C.c_int32 * 1)(0)
+    uid = (C.c_uint8 * L.COMM_UNIQUE_ID_BYTES)()
+    L.check(L.lib().mi355q_comm_get_unique_id(uid))
+    L.check(L.lib().mi355q_comm_init_rank(grp, 1, uid, 0))
+    assert L.lib().mi355q_comm_exists(grp, 1) == 1
+    L.check(L.lib().mi355q_comm_init_rank(grp, 1, uid, 0))  # a group that has a communicator is left alone (:54)
+    try:
+        for dtype in (torch.float16, torch.bfloat16, torch.float32):
+            x = torch.randn(4096 * 33, device=cuda).to(dtype)
+            for strat in (L.AR_RING, L.AR_AUTO):
+                plg = Plugin("AllReduce", [("group", [0], L.FIELD_INT32), ("type_id", torch_dtype_to_trt(dtype), L.FIELD_INT32),
+                                           ("strategy", strat, L.FIELD_INT8), ("counter", 0, L.FIELD_INT32)])
+                plg = Plugin.deserialize("AllReduce", plg.serialize())
+                y = torch.zeros_like(x)
+                if strat == L.AR_RING:
+                    plg.enqueue([x], [y])
+                else:  # AUTO with comm buffers of 64 KiB: the 270 KB / 540 KB message goes to RING (:115-118)
+                    table = torch.tensor([1, 2, 3, 4, 5, 6, 7, 8, 65536, 0], dtype=torch.int64)
+                    plg = Plugin("AllReduce", [("group", [0, 1], L.FIELD_INT32), ("type_id", torch_dtype_to_trt(dtype), L.FIELD_INT32),
+                                               ("strategy", strat, L.FIELD_INT8), ("counter", 0, L.FIELD_INT32), ("rank", 0, L.FIELD_INT32)])
+                    with pytest.raises(L.Mi355qError, match="mi355q_comm_init_rank"):   # group {0, 1} has no communicator
+                        plg.enqueue([x, table], [y])
+                    continue
+                torch.cuda.synchronize()
+                assert torch.equal(x, y)
+        x = torch.randint(-100, 100, (5, 3), dtype=torch.int8, device=cuda)   # 15 bytes: any size goes through RCCL
+        ag = Plugin.deserialize("AllGather", Plugin("AllGather", [("group", [0], L.FIELD_INT32), ("type_id", L.INT8, L.FIELD_INT32)]).serialize())
+        y = torch.zeros_like(x)
+        ag.enqueue([x], [y])
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    finally:
+        L.check(L.lib().mi355q_comm_destroy(grp, 1))
+    assert L.lib().mi355q_comm_exists(grp, 1) == 0

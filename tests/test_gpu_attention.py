@@ -176,6 +176,14 @@ def test_decode_long_multi_block(cuda):
     check(1, 1, 1, 128, [4097], 64, torch.float16, torch.float16, cuda)
 
 
+def test_decode_cfg5_instantiation(cuda):
+    # the exact kernel BASELINE cfg5 times: bf16 activations, fp8 e4m3 cache, 4 query heads per kv head (Mixtral 32q / 8kv),
+    # split-KV lengths; and the same group with an int8 cache
+    check(2, 32, 8, 128, [2049, 700], 64, torch.bfloat16, torch.float8_e4m3fn, cuda)
+    check(2, 32, 8, 128, [2049, 700], 64, torch.bfloat16, torch.float8_e4m3fn, cuda, rope="neox")
+    check(2, 32, 8, 128, [1030, 65], 64, torch.bfloat16, torch.int8, cuda)
+
+
 def test_decode_remove_padding_and_layer_offset(cuda):
     # packed input layout + block-pointer slicing by layer_idx (gptAttentionPlugin.cpp:506-519)
     check(3, 4, 2, 128, [9, 200, 70], 64, torch.float16, torch.float16, cuda, remove_padding=True, num_layers=3,

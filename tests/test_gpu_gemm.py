@@ -99,7 +99,7 @@ def test_w4a8_awq_groupwise_quant_matmul(cuda, dtype_str, m, n, k, pre, zero, bi
 
 
 @pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
-@pytest.mark.parametrize("m", [1, 4, 16])
+@pytest.mark.parametrize("m", [1, 2, 4, 8, 16])
 def test_groupwise_baseline_cfg1_shape(cuda, dtype_str, m):
     # BASELINE cfg1: N = K = 4096, g = 128, zeros + pre-quant scale
     _groupwise_case(m, 4096, 4096, dtype_str, True, True, False, 128, cuda)

@@ -249,7 +249,6 @@ def test_allreduce_plugin_fields_serialization_and_deserialize_params():
     assert np.frombuffer(blob[9:], np.int32).tolist() == [0, 1, 2, 3]
     assert Plugin.deserialize("AllReduce", blob).serialize() == blob
     assert plg.get_output_dimensions(0, [[5, 8192], [16]]) == [5, 8192]
-    # RING is the host's RCCL call: the plugin says so instead of running something else
     # AllGather (allgatherPlugin.cpp:36-54, :66-72, :147-160): type then the group; dim 0 times the group size
     ag = Plugin("AllGather", [("group", [0, 1, 2, 3], L.FIELD_INT32), ("type_id", L.HALF, L.FIELD_INT32)])
     assert ag.get_output_dimensions(0, [[6, 5, 7], [18]]) == [24, 5, 7]
@@ -259,10 +258,18 @@ def test_allreduce_plugin_fields_serialization_and_deserialize_params():
         Plugin("AllGather", [("type_id", L.HALF, L.FIELD_INT32)])
     ring = Plugin("AllReduce", [("group", [0, 1], L.FIELD_INT32), ("type_id", L.HALF, L.FIELD_INT32),
                                 ("strategy", L.AR_RING, L.FIELD_INT8), ("counter", 0, L.FIELD_INT32)])
-    with pytest.raises(L.Mi355qError, match="RING"):
+    # RING = ncclAllReduce on the group's communicator (allreducePlugin.cpp:181-185); without one the plugin says which
+    # call is missing instead of running something else.  Same for the reference's one-input AllGather.
+    with pytest.raises(L.Mi355qError, match="mi355q_comm_init_rank"):
         ring.enqueue([torch.zeros(8, dtype=torch.float16)], [torch.zeros(8, dtype=torch.float16)])
-    # AllReduceParams::deserialize: even flags use the ping buffers, odd the pong buffers
-    import ctypes as C
+    with pytest.raises(L.Mi355qError, match="mi355q_comm_init_rank"):
+        Plugin.deserialize("AllGather", agblob).enqueue([torch.zeros(8, dtype=torch.float16)],
+                                                        [torch.zeros(32, dtype=torch.float16)])
+    grp = (C.c_int32 * 2)(0, 1)
+    assert L.lib().mi355q_comm_exists(grp, 2) == 0
+    L.check(L.lib().mi355q_comm_destroy(grp, 2))          # nothing to destroy: not an error (terminate, :254-267)
+    assert L.lib().mi355q_comm_exists((C.c_int32 * 2)(1, 1), 2) < 0   # a rank twice
+    # AllReduceParams::deserialize: even flags name the ping buffers, odd the pong buffers; both sets travel
     tp = 4
     table = (C.c_void_p * (4 * tp))(*[0x1000 * (i + 1) for i in range(4 * tp)])
     prm = L.AllReduceParams()
@@ -272,6 +279,10 @@ def test_allreduce_plugin_fields_serialization_and_deserialize_params():
     assert (prm.ranks_per_node, prm.rank, prm.local_rank, prm.barrier_flag) == (4, 2, 2, 6)
     L.check(L.lib().mi355q_allreduce_params_deserialize(C.byref(prm), table, tp, 1, 7))
     assert prm.peer_comm_buffer_ptrs[0] == 0x1000 * (tp + 1)
+    assert [prm.peer_comm_buffer_ptrs_ping[i] for i in range(tp)] == [0x1000 * (i + 1) for i in range(tp)]
+    assert [prm.peer_comm_buffer_ptrs_pong[i] for i in range(tp)] == [0x1000 * (tp + i + 1) for i in range(tp)]
+    # flags per (phase, rank, workgroup) + the rank's epoch and arrival lines
+    assert L.lib().mi355q_allreduce_barrier_bytes() == (2 * 8 * 256 + 64) * 4
     assert L.lib().mi355q_allreduce_max_workspace_size(2) == 16_000_000
     assert L.lib().mi355q_allreduce_max_workspace_size(8) == 8_000_000
 
