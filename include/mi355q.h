@@ -470,7 +470,10 @@ extern "C"
      * (checked against the message), a host-visible word that receives 1 when a peer never arrived (or NULL), the
      * wall-clock bound of every wait in milliseconds (0 = 30000), and BOTH sets of comm buffers: the kernels choose
      * ping or pong by their own epoch, barrier_flag / peer_comm_buffer_ptrs keep the reference's meaning and are not
-     * read by them.  All ranks must issue the same sequence of collectives on these buffers, one stream at a time. */
+     * read by them.  All ranks must issue the same sequence of collectives on these buffers, one stream at a time.
+     * A workgroup that waits for its peers keeps its place on the CU, so all ranks' workgroups of a collective must be
+     * resident together: always true with one rank per GPU; ranks that share a GPU (one-GPU rehearsals) set
+     * max_workgroups so that ranks x max_workgroups x 256 threads fit the chip (e.g. 64 for 8 ranks). */
     typedef struct
     {
         size_t elts_total;
@@ -489,6 +492,7 @@ extern "C"
         uint32_t timeout_ms;
         void* peer_comm_buffer_ptrs_ping[MI355Q_MAX_RANKS_PER_NODE];
         void* peer_comm_buffer_ptrs_pong[MI355Q_MAX_RANKS_PER_NODE];
+        uint32_t max_workgroups; /* 0 = MI355Q_AR_MAX_WORKGROUPS; lower it when several ranks share one GPU */
     } mi355q_allreduce_params;
     /* AllReduceParams::deserialize(buffer, tpSize, tpRank, flag_value) (customAllReduceKernels.cu:398-425):
      * buffer_ptrs = HOST array [4 * tpSize]: ping buffers | pong buffers | barrier-in | barrier-out, one per rank */
@@ -509,9 +513,11 @@ extern "C"
         int32_t strategy, void* stream);
     /* invokeMultiGpuBarrier (:391-394) over peer_barrier_ptrs_out */
     mi355q_status mi355q_multi_gpu_barrier(const mi355q_allreduce_params* params, void* stream);
-    /* No counterpart in the reference (its flag spins are unbounded): a zeroed host-visible word for
-     * mi355q_allreduce_params.timeout_flag / the AllReduce plugin's workspace table; the kernels set it to 1 when a
-     * wait for a peer ran out of time (their output is then NaN), the host may read it at any time. */
+    /* No counterpart in the reference (its flag spins are unbounded): a zeroed host-visible record of FOUR words for
+     * mi355q_allreduce_params.timeout_flag / the AllReduce plugin's workspace table; the kernels set word 0 to 1 when a
+     * wait for a peer ran out of time (their output is then NaN) and leave in words 1..3 which wait it was
+     * (phase << 16 | peer rank << 8 | workgroup & 255, the flag value waited for, the value found); the host may read
+     * it at any time.  A caller that passes its own memory must provide those 16 bytes. */
     mi355q_status mi355q_allreduce_alloc_timeout_flag(uint32_t** flag);
     mi355q_status mi355q_allreduce_free_timeout_flag(uint32_t* flag);
     /* IpcMemory (tensorrt_llm/_ipc_utils.py:66-133; cpp/tensorrt_llm/runtime/ipcUtils.cpp): set-up time helpers --

@@ -169,10 +169,18 @@ __device__ __forceinline__ bool publish_and_wait(const ArArgs& p, uint32_t flag,
     if (tid < RANKS)
     {
         flag_store(p.barrier_in[tid] + ((size_t) (phase * RANKS + p.rank) * AR_MAX_WGS + w), flag);
-        if (!flag_wait(p.barrier_in[p.rank] + ((size_t) (phase * RANKS + tid) * AR_MAX_WGS + w), flag, p.timeout_ticks))
+        uint32_t* const mine = p.barrier_in[p.rank] + ((size_t) (phase * RANKS + tid) * AR_MAX_WGS + w);
+        if (!flag_wait(mine, flag, p.timeout_ticks))
         {
             if (p.timeout_flag)
+            {
+                // words 1..3 of the 64-byte timeout record say who was missing (the last lane to give up wins):
+                // phase << 16 | peer << 8 | workgroup, the flag waited for, the value found
+                p.timeout_flag[1] = (uint32_t) phase << 16 | (uint32_t) tid << 8 | (uint32_t) (w & 255);
+                p.timeout_flag[2] = flag;
+                p.timeout_flag[3] = __hip_atomic_load((ar_gu32*) mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(p.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             *failed_lds = 1;
         }
     }
@@ -354,6 +362,15 @@ size_t round_up(size_t a, size_t b)
     return div_up(a, b) * b;
 }
 
+// A workgroup that waits for its peers holds its slot on the CU until they arrive, so every rank's workgroups must be
+// resident at once.  On a node each rank has its own GPU and 256 workgroups of 256 threads always are; ranks that SHARE
+// one GPU (the one-GPU tests: 8 ranks x 256 workgroups are more than the chip holds, measured: deadlock until the
+// bounded wait expires) bound the count through params.max_workgroups.
+size_t max_workgroups(const mi355q_allreduce_params& q)
+{
+    return q.max_workgroups ? std::min<size_t>(q.max_workgroups, AR_MAX_WGS) : (size_t) AR_MAX_WGS;
+}
+
 void check_params(const mi355q_allreduce_params& q)
 {
     MQ_CHECK(q.ranks_per_node >= 2 && q.ranks_per_node <= MI355Q_MAX_RANKS_PER_NODE, "ranks_per_node %zu", q.ranks_per_node);
@@ -392,6 +409,7 @@ void invoke(mi355q_allreduce_params& q, int strat, hipStream_t stream)
     const size_t comm_bytes = q.comm_buffer_bytes ? q.comm_buffer_bytes : mi355q_allreduce_max_workspace_size((int) ranks);
     ArArgs a = to_args(q);
     a.total_bytes = total;
+    const size_t max_wgs = max_workgroups(q);
     // the caller's contract (allreducePlugin.cpp:195-199) is "input already in my comm buffer"; with local_input_buffer_ptr
     // the kernel reads the input where it lies instead.  The staged copy sits at the start of the own buffer, which is
     // scatter slot / one-shot slot 0: for rank != 0 another rank overwrites it, so it is read from a private copy only
@@ -406,7 +424,7 @@ void invoke(mi355q_allreduce_params& q, int strat, hipStream_t stream)
         a.slot_bytes = round_up(total, 256);
         MQ_CHECK(ranks * a.slot_bytes <= comm_bytes, "one-shot all-reduce of %zu bytes x %zu ranks exceeds the %zu-byte comm buffer",
             total, ranks, comm_bytes);
-        blocks = (int) std::min<size_t>(AR_MAX_WGS, std::max<size_t>(1, div_up(total, AR_MIN_CHUNK)));
+        blocks = (int) std::min<size_t>(max_wgs, std::max<size_t>(1, div_up(total, AR_MIN_CHUNK)));
         a.chunk_bytes = round_up(div_up(total, blocks), 16);
         q.elts_per_rank = q.elts_total;
         q.rank_offset = 0;
@@ -419,7 +437,7 @@ void invoke(mi355q_allreduce_params& q, int strat, hipStream_t stream)
         MQ_CHECK(2 * total <= comm_bytes, "two-shot all-reduce of %zu bytes needs a %zu-byte comm buffer, have %zu", total,
             2 * total, comm_bytes);
         a.slot_bytes = slice;
-        blocks = (int) std::min<size_t>(AR_MAX_WGS, std::max<size_t>(1, div_up(slice, AR_MIN_CHUNK)));
+        blocks = (int) std::min<size_t>(max_wgs, std::max<size_t>(1, div_up(slice, AR_MIN_CHUNK)));
         a.chunk_bytes = round_up(div_up(slice, blocks), 16);
         q.elts_per_rank = q.elts_total / ranks;
         q.rank_offset = q.local_rank * q.elts_per_rank;
@@ -505,7 +523,7 @@ void custom_all_gather(mi355q_allreduce_params& q, const void* in, void* out, si
     a.slot_bytes = round_up(bytes_per_rank, 256);
     MQ_CHECK(ranks * a.slot_bytes <= comm_bytes, "all-gather of %zu bytes x %zu ranks exceeds the %zu-byte comm buffer",
         bytes_per_rank, ranks, comm_bytes);
-    const int blocks = (int) std::min<size_t>(AR_MAX_WGS, std::max<size_t>(1, div_up(bytes_per_rank, AR_MIN_CHUNK)));
+    const int blocks = (int) std::min<size_t>(max_workgroups(q), std::max<size_t>(1, div_up(bytes_per_rank, AR_MIN_CHUNK)));
     a.chunk_bytes = round_up(div_up(bytes_per_rank, blocks), 16);
     switch (ranks)
     {

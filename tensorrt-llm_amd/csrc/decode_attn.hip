@@ -728,7 +728,7 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
         MQ_CHECK(((uintptr_t) q.workspace & 127) == 0, "workspace must be 128-byte aligned");
         a.group_floats = (int) group_floats(q, pl);
         a.partials = reinterpret_cast<float*>(q.workspace);
-        a.arrivals = arrival_lines((size_t) pl.groups);
+        a.arrivals = arrival_lines((size_t) pl.groups, stream);
     }
 #ifdef MI355Q_LAB
     a.stamps = lab_decode_stamps();

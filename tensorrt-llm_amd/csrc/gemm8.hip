@@ -651,6 +651,350 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent / stream-K form of the phased kernel (round 3).  The phased kernel runs one 256 x 256
+// tile per workgroup and one workgroup per CU, so a problem of T tiles takes ceil(T / 256) rounds whatever T % 256 is:
+// cfg3 (4096 x 13824 x 5120) is 864 tiles = 3.375 rounds of work in 4 rounds of time (the round-2 remedy, a second
+// launch with smaller tiles for the last columns, took 107 us for 0.375 rounds).  Here `grid` workgroups stay resident:
+//   * the first floor(T / grid) * grid tiles are walked one per workgroup and round with the phased loop (same XCD
+//     chunks and grouped rasterisation);
+//   * the K-tiles of the remaining R tiles form ONE sequence of R * nk iterations, cut into equal runs of `sk_iters`,
+//     one run per workgroup (the stream-K decomposition: every CU gets the same number of K-tiles).  A run that ends
+//     inside a tile leaves a partial accumulator: the workgroup stores its 256 x 256 image (fragment order, 16-byte
+//     write-through stores), drains, and raises its flag.  The workgroup that holds the tile's LAST K-tiles adds the
+//     images of the others to its registers and runs the epilogue.  int32 sums are exact in any order, so the
+//     SmoothQuant result is bit-identical to the one-pass kernel's; fp8 sums partial fp32 sums in a fixed order.
+// A finishing workgroup only ever waits for workgroups with a LOWER index, and those never wait for it: workgroups are
+// dispatched in index order, so what it waits for is running or done whatever else occupies the chip -- no deadlock,
+// no co-residency requirement.  Every workgroup first runs the segment it must hand over and finishes a tile last, so
+// the hand-over is ready long before it is asked for.  The wait is bounded all the same (8 s of s_memrealtime): on
+// expiry the tile is poisoned (NaN / INT_MIN).  Flags are arrival_ring words (zero at launch, put back to zero by the
+// consumer).  Requires m % 256 == 0, n % 256 == 0, k % 128 == 0.
+struct SkArgs
+{
+    int grid;           // workgroups launched (<= 256; a multiple of 8 when dp_rounds > 0)
+    int dp_rounds;      // whole rounds of `grid` tiles
+    int sk_tiles;       // tiles after them, cut over K
+    int sk_iters;       // K-tiles per workgroup in the stream-K part
+    uint32_t* partials; // [workgroup][256 * 256] accumulator images
+    uint32_t* flags;    // one word per workgroup, ARRIVAL_WORD_STRIDE apart
+};
+
+template <bool FP8>
+__global__ __launch_bounds__(512) void gemm8_sk_kernel(Gemm8Args g, int tiles_m, int tiles_n, int group_m, SkArgs sk)
+{
+    typedef typename std::conditional<FP8, f32x4_t, i32x4_t>::type acc_t;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    typedef __attribute__((address_space(1))) uint32_t gu32_t;
+    constexpr int TK = 128;
+    constexpr int UNIT = 128 * TK;
+    constexpr size_t IMAGE_BYTES = (size_t) 256 * 256 * 4;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * UNIT];
+    __shared__ int sk_ok;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nk = g.k / TK;
+    const int b = blockIdx.x;
+
+    // fragment addressing (see gemm8_phased_kernel)
+    const int frow = lane & 15, fk = lane >> 4;
+    const int fsw = (frow >> 1) & 7;
+    const int c0 = FP8 ? 2 * fk : fk, c1 = FP8 ? 2 * fk + 1 : 4 + fk;
+    const int off_k0 = frow * TK + ((c0 ^ fsw) << 4), off_k1 = frow * TK + ((c1 ^ fsw) << 4);
+    const int a_row0 = wr * 64 * TK;
+    const int b_row0 = wc * 32 * TK;
+    const int em = lane & 15, en = (lane >> 4) * 4;
+
+    // this workgroup's run of the stream-K iteration space: tiles tA .. tB, from K-tile kA of tA to kB (exclusive) of tB
+    const int dp_tiles = sk.dp_rounds * sk.grid;
+    const int it0 = b * sk.sk_iters, it1 = min(it0 + sk.sk_iters, sk.sk_tiles * nk);
+    int nseg = 0, tA = 0, kA = 0, tB = 0, kB = 0;
+    if (it0 < it1)
+    {
+        tA = it0 / nk, kA = it0 - tA * nk;
+        tB = (it1 - 1) / nk, kB = it1 - tB * nk;
+        nseg = tB - tA + 1;
+    }
+    const int nwork = sk.dp_rounds + nseg;
+
+#define P8_BARRIER()                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+    } while (0)
+#define P8_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define P8_WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    for (int work = 0; work < nwork; ++work)
+    {
+        int lin, k0, k1;
+        if (work < sk.dp_rounds)
+        {
+            lin = (b & 7) * (dp_tiles >> 3) + work * (sk.grid >> 3) + (b >> 3); // an XCD walks its own chunk of tiles
+            k0 = 0, k1 = nk;
+        }
+        else
+        {
+            const int t = tB - (work - sk.dp_rounds); // last tile of the run first: that one is handed over
+            lin = dp_tiles + t;
+            k0 = t == tA ? kA : 0;
+            k1 = t == tB ? kB : nk;
+        }
+        const int per_group = group_m * tiles_n;
+        const int first_tm = (lin / per_group) * group_m;
+        const int gsz = min(group_m, tiles_m - first_tm);
+        const int tm = first_tm + (lin % per_group) % gsz, tn = (lin % per_group) / gsz;
+        const size_t m0 = (size_t) tm * 256, n0 = (size_t) tn * 256;
+        const int nkt = k1 - k0;
+
+        const uint8_t* usrc[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int u = (wave * 2 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((u >> 1) & 7);
+            const size_t ra = m0 + (u >> 6) * 128 + (u & 63);
+            const size_t rb = n0 + (u >> 5) * 64 + (u & 31);
+            const size_t koff = (size_t) k0 * TK + chunk * 16;
+            usrc[0][i] = g.A + ra * g.k + koff;
+            usrc[3][i] = g.A + (ra + 64) * g.k + koff;
+            usrc[1][i] = g.B + rb * g.k + koff;
+            usrc[2][i] = g.B + (rb + 32) * g.k + koff;
+        }
+        auto stage = [&](int unit, int kt)
+        {
+            const int t = min(kt, nkt - 1);
+            uint8_t* dst = lds + ((kt & 1) * 4 + unit) * UNIT + wave * 2048;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*) (usrc[unit][0] + (size_t) t * TK), (lds_void_t*) dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (gbl_void_t*) (usrc[unit][1] + (size_t) t * TK), (lds_void_t*) (dst + 1024), 16, 0, 0);
+        };
+
+        acc_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = acc_t{0, 0, 0, 0};
+        i32x4_t fa[4][2], fb0[2][2], fb1[2][2], fb0n[2][2];
+
+        auto read_a = [&](const uint8_t* unit_base)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                fa[i][0] = *reinterpret_cast<const i32x4_t*>(unit_base + a_row0 + i * 16 * TK + off_k0);
+                fa[i][1] = *reinterpret_cast<const i32x4_t*>(unit_base + a_row0 + i * 16 * TK + off_k1);
+            }
+        };
+        auto read_b = [&](i32x4_t (&fb)[2][2], const uint8_t* unit_base)
+        {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+            {
+                fb[j][0] = *reinterpret_cast<const i32x4_t*>(unit_base + b_row0 + j * 16 * TK + off_k0);
+                fb[j][1] = *reinterpret_cast<const i32x4_t*>(unit_base + b_row0 + j * 16 * TK + off_k1);
+            }
+        };
+        auto mfma_quadrant = [&](int mq, int nq, const i32x4_t (&fb)[2][2])
+        {
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (FP8)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                    {
+                        const i32x8_t w = __builtin_shufflevector(fb[j][0], fb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const i32x8_t x = __builtin_shufflevector(fa[i][0], fa[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[mq * 4 + i][nq * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            w, x, acc[mq * 4 + i][nq * 2 + j], 0, 0, 0, 0, 0, 0);
+                    }
+            }
+            else
+            {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[mq * 4 + i][nq * 2 + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                fb[j][ks], fa[i][ks], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+
+        // the phased loop of gemm8_phased_kernel over K-tiles k0 .. k1 - 1
+        stage(0, 0);
+        stage(1, 0);
+        stage(2, 0);
+        stage(3, 0);
+        stage(0, 1);
+        stage(1, 1);
+        P8_WAIT_VM8();
+        P8_BARRIER();
+        if (wr == 1)
+            P8_BARRIER();
+        read_b(fb0, lds + 1 * UNIT);
+        for (int kt = 0; kt < nkt; ++kt)
+        {
+            const uint8_t* buf = lds + (kt & 1) * 4 * UNIT;
+            const uint8_t* nbuf = lds + ((kt + 1) & 1) * 4 * UNIT;
+            read_a(buf + 0 * UNIT);
+            stage(2, kt + 1);
+            P8_WAIT_VM8();
+            P8_BARRIER();
+            P8_WAIT_LGKM0();
+            mfma_quadrant(0, 0, fb0);
+            P8_BARRIER();
+            read_b(fb1, buf + 2 * UNIT);
+            stage(3, kt + 1);
+            P8_WAIT_VM8();
+            P8_BARRIER();
+            P8_WAIT_LGKM0();
+            mfma_quadrant(0, 1, fb1);
+            P8_BARRIER();
+            read_a(buf + 3 * UNIT);
+            stage(0, kt + 2);
+            P8_WAIT_VM6();
+            P8_BARRIER();
+            P8_WAIT_LGKM0();
+            mfma_quadrant(1, 1, fb1);
+            P8_BARRIER();
+            read_b(fb0n, nbuf + 1 * UNIT);
+            stage(1, kt + 2);
+            P8_WAIT_VM8();
+            P8_BARRIER();
+            mfma_quadrant(1, 0, fb0);
+            P8_WAIT_LGKM0();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+            {
+                fb0[j][0] = fb0n[j][0];
+                fb0[j][1] = fb0n[j][1];
+            }
+            P8_BARRIER();
+        }
+        if (wr == 0)
+            P8_BARRIER();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        if (k1 < nk)
+        {
+            // hand the partial tile over: image of workgroup b, value (i, j) of thread tid at ((i * 4 + j) * 512 + tid) * 16
+            const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+                (void*) (reinterpret_cast<uint8_t*>(sk.partials) + (size_t) b * IMAGE_BYTES), 0, (int) IMAGE_BYTES, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(u32x4_t, acc[i][j]), img, ((i * 4 + j) * 512 + tid) * 16, 0, 16 /* sc1 */);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave, before the barrier the signalling lane passes
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store((gu32_t*) (sk.flags + (size_t) b * ARRIVAL_WORD_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue; // (the barrier above also released the LDS)
+        }
+        if (k0 > 0)
+        {
+            // the tile's last K-tiles are here: add what the workgroups before this one left
+            const int first = ((lin - dp_tiles) * nk) / sk.sk_iters;
+            if (tid == 0)
+            {
+                int ok = 1;
+                for (int c = first; c < b; ++c)
+                {
+                    gu32_t* f = (gu32_t*) (sk.flags + (size_t) c * ARRIVAL_WORD_STRIDE);
+                    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    {
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 800000000ull) // 8 s at 100 MHz
+                        {
+                            ok = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // clean for the next launch
+                }
+                sk_ok = ok;
+            }
+            __syncthreads();
+            const bool ok = sk_ok != 0;
+            for (int c = first; c < b; ++c)
+            {
+                const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*) (reinterpret_cast<uint8_t*>(sk.partials) + (size_t) c * IMAGE_BYTES), 0, (int) IMAGE_BYTES, 0x00020000);
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                {
+                    u32x4_t v[16]; // 16 loads in flight (the fragment registers are free here)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        v[q] = __builtin_amdgcn_raw_buffer_load_b128(img, ((half * 16 + q) * 512 + tid) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        acc[half * 4 + q / 4][q % 4] += __builtin_bit_cast(acc_t, v[q]);
+                }
+            }
+            if (!ok)
+            {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        if constexpr (FP8)
+                            acc[i][j] = acc_t{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                        else
+                            acc[i][j] = acc_t{INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+                    }
+            }
+        }
+
+        // epilogue (gemm8_phased_kernel's)
+        float sr[8], sc[4][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            sr[i] = g.alpha_row[g.per_token ? m0 + wr * 128 + i * 16 + em : 0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            gemm8_col_scales(g, n0 + wc * 64 + j * 16 + en, sc[j]);
+        gemm8_dispatch_out(g.out_type, [&](auto out)
+        {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                const size_t row = m0 + wr * 128 + i * 16 + em;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const size_t col = n0 + wc * 64 + j * 16 + en;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = (float) acc[i][j][r] * (sc[j][r] * sr[i]);
+                    gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
+                }
+            }
+        });
+        __syncthreads(); // the LDS (and sk_ok) are free for the next tile
+    }
+#undef P8_BARRIER
+#undef P8_WAIT_VM8
+#undef P8_WAIT_VM6
+#undef P8_WAIT_LGKM0
+}
+
 #ifdef MI355Q_LAB
 // ---------------------------------------------------------------------------------------------
 // LAB BUILD ONLY -- the experiment VERDICT r1 asked for, kept so that its A/B can be re-run (tools/lab_gemm8_ab.py,

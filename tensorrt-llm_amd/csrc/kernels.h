@@ -36,7 +36,10 @@ void weight_only_gemv_light(const mi355q_weight_only_params& p, LightPlan pl, vo
 // arrival_ring.hip: zero-initialised, self-resetting arrival words of in-launch reductions, one per 128-byte line
 constexpr int ARRIVAL_WORD_STRIDE = 32; // uint32 words between two arrival words
 size_t arrival_lines_max();
-uint32_t* arrival_lines(size_t count); // device pointer (current device) to `count` words, ARRIVAL_WORD_STRIDE apart
+// device pointer (current device) to `count` zero words, ARRIVAL_WORD_STRIDE apart, that no launch able to overlap with
+// one on `stream` (another stream's, another captured graph's) counts on
+uint32_t* arrival_lines(size_t count, hipStream_t stream);
+void arrival_words_prepare(); // resolve the current device's array now (plugin configure), not inside the first enqueue
 
 // woq_prefill.hip
 struct WoqArgsHost

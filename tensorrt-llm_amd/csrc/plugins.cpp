@@ -707,12 +707,13 @@ struct AllReducePlugin : PluginBase
             comm_all_reduce(mGroup.data(), (int) mGroup.size(), inputs[0], outputs[0], (size_t) size, mType, stream);
             return;
         }
-        // the workspace table: 4 pointers per rank (NUM_POINTERS_PER_RANK), optionally followed by two more entries this
-        // library's CustomAllReduceHelper appends: the byte size of a comm buffer and the host-visible timeout word
+        // the workspace table: 4 pointers per rank (NUM_POINTERS_PER_RANK), optionally followed by the entries this
+        // library's CustomAllReduceHelper appends: the byte size of a comm buffer, the host-visible timeout record, and
+        // (third, optional) the workgroup bound for ranks that share one GPU
         const int len = inDesc[1].dims.d[0];
         const int nRanks = (int) mGroup.size();
-        MQ_CHECK(nRanks >= 2 && (len == 4 * nRanks || len == 4 * nRanks + 2), "all_reduce_workspace length %d for %d ranks",
-            len, nRanks);
+        MQ_CHECK(nRanks >= 2 && len >= 4 * nRanks && len <= 4 * nRanks + 3 && len != 4 * nRanks + 1,
+            "all_reduce_workspace length %d for %d ranks", len, nRanks);
         const int64_t* table = static_cast<const int64_t*>(inputs[1]);
         int myRank = mRank;
         if (myRank < 0)
@@ -726,8 +727,10 @@ struct AllReducePlugin : PluginBase
         allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, mCounter);
         params.local_input_buffer_ptr = inputs[0]; // pushed to the peers by the kernel: no staging copy (allreducePlugin.cpp:195-199)
         params.comm_buffer_bytes = mi355q_allreduce_max_workspace_size(nRanks);
-        if (len == 4 * nRanks + 2)
+        if (len >= 4 * nRanks + 2)
         {
+            if (len == 4 * nRanks + 3)
+                params.max_workgroups = (uint32_t) table[4 * nRanks + 2];
             params.comm_buffer_bytes = (size_t) table[4 * nRanks];
             params.timeout_flag = reinterpret_cast<uint32_t*>(table[4 * nRanks + 1]);
             if (params.timeout_flag)
@@ -815,8 +818,8 @@ struct AllGatherPlugin : PluginBase
             return;
         }
         const int len = inDesc[1].dims.d[0];
-        MQ_CHECK(nRanks >= 2 && (len == 4 * nRanks || len == 4 * nRanks + 2), "all_reduce_workspace length %d for %d ranks",
-            len, nRanks);
+        MQ_CHECK(nRanks >= 2 && len >= 4 * nRanks && len <= 4 * nRanks + 3 && len != 4 * nRanks + 1,
+            "all_reduce_workspace length %d for %d ranks", len, nRanks);
         const int64_t* table = static_cast<const int64_t*>(inputs[1]);
         int myRank = mRank;
         if (myRank < 0)
@@ -829,8 +832,10 @@ struct AllGatherPlugin : PluginBase
         mi355q_allreduce_params params;
         allreduce_params_deserialize(params, static_cast<const void* const*>(inputs[1]), nRanks, myRank, 0);
         params.comm_buffer_bytes = mi355q_allreduce_max_workspace_size(nRanks);
-        if (len == 4 * nRanks + 2)
+        if (len >= 4 * nRanks + 2)
         {
+            if (len == 4 * nRanks + 3)
+                params.max_workgroups = (uint32_t) table[4 * nRanks + 2];
             params.comm_buffer_bytes = (size_t) table[4 * nRanks];
             params.timeout_flag = reinterpret_cast<uint32_t*>(table[4 * nRanks + 1]);
             if (params.timeout_flag)
@@ -1882,6 +1887,13 @@ extern "C"
             {
                 MQ_CHECK(p && in, "null argument");
                 p->impl->configure(in, nbInputs, out, nbOutputs);
+                // resolve this GPU's arrival-word array now, not inside the first enqueue (which may run under stream
+                // capture); a build machine without a GPU configures plugins too
+                int devices = 0;
+                if (hipGetDeviceCount(&devices) == hipSuccess && devices > 0)
+                    arrival_words_prepare();
+                else
+                    (void) hipGetLastError();
             });
     }
 

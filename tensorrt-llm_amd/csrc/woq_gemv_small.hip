@@ -651,7 +651,7 @@ void weight_only_gemv_light(const mi355q_weight_only_params& p, LightPlan pl, vo
     if (pl.ksplit > 1)
     {
         la.records = reinterpret_cast<float*>(workspace);
-        la.arrivals = arrival_lines((size_t) nblocks);
+        la.arrivals = arrival_lines((size_t) nblocks, stream);
     }
     static const int lab_abl = lab_env("MI355Q_GEMV_LIGHT_ABL") ? atoi(lab_env("MI355Q_GEMV_LIGHT_ABL")) : 0;
     la.abl = lab_abl;

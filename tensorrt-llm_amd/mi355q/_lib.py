@@ -145,6 +145,7 @@ class AllReduceParams(C.Structure):
         ("local_input_buffer_ptr", C.c_void_p), ("comm_buffer_bytes", C.c_size_t), ("timeout_ms", C.c_uint32),
         ("peer_comm_buffer_ptrs_ping", C.c_void_p * MAX_RANKS_PER_NODE),
         ("peer_comm_buffer_ptrs_pong", C.c_void_p * MAX_RANKS_PER_NODE),
+        ("max_workgroups", C.c_uint32),
     ]
 
 

@@ -97,7 +97,9 @@ class CustomAllReduceHelper:
     def max_workspace_size_auto(tp_size):
         return L.lib().mi355q_allreduce_max_workspace_size(tp_size)
 
-    def __init__(self, size=None, group=None, timeout_ms=0):
+    def __init__(self, size=None, group=None, timeout_ms=0, max_workgroups=0):
+        """`max_workgroups`: 0 = one per CU.  Ranks that share ONE GPU (rehearsals, the one-GPU tests) must bound it so
+        that all ranks' workgroups are resident at once -- a workgroup waiting for its peers keeps its slot."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -113,7 +115,8 @@ class CustomAllReduceHelper:
         for b in self.buffers:
             ptrs += b.serialize()
         # the reference's table (4 pointers per rank) + the comm-buffer byte size + the timeout word
-        self.workspace = torch.tensor(ptrs + [size, self._timeout_flag], dtype=torch.int64, device="cpu")
+        self.max_workgroups = max_workgroups
+        self.workspace = torch.tensor(ptrs + [size, self._timeout_flag, max_workgroups], dtype=torch.int64, device="cpu")
         self.counter = 0
         self._ranks = (C.c_int32 * self.world)(*range(self.world))
 
@@ -124,16 +127,22 @@ class CustomAllReduceHelper:
     def timed_out(self):
         return C.cast(self._timeout_flag, C.POINTER(C.c_uint32))[0] != 0
 
+    def timeout_info(self):
+        """Which wait ran out of time: (phase, peer rank, workgroup & 255, flag waited for, value found)."""
+        w = C.cast(self._timeout_flag, C.POINTER(C.c_uint32))
+        return (w[1] >> 16, (w[1] >> 8) & 255, w[1] & 255, w[2], w[3])
+
     def close(self):
         if torch.cuda.is_available():
             torch.cuda.synchronize()   # a collective still in flight may write the host-mapped timeout word
         dist.barrier(group=self.group)
-        timed_out = self.timed_out()
+        timed_out, info = self.timed_out(), self.timeout_info()
         for b in self.buffers:
             b.close()
         L.lib().mi355q_allreduce_free_timeout_flag(self._timeout_flag)
         if timed_out:
-            raise RuntimeError("custom all-reduce: a wait for a peer rank timed out during this session")
+            raise RuntimeError("custom all-reduce: a wait for a peer rank timed out during this session "
+                               "(phase %d, peer %d, workgroup %d, flag %d, found %d)" % info)
 
     def _params(self, tensor, out):
         """AllReduceParams for the direct launcher (mi355q_custom_all_reduce), same state as the plugin path."""
@@ -144,6 +153,7 @@ class CustomAllReduceHelper:
         p.comm_buffer_bytes = self.size
         p.timeout_flag = self._timeout_flag
         p.timeout_ms = self.timeout_ms
+        p.max_workgroups = self.max_workgroups
         return p
 
     def allreduce(self, tensor, strategy=L.AR_AUTO, out=None, direct=False):

@@ -100,7 +100,10 @@ def _worker(rank, world, port, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ok, msg = True, ""
     try:
-        helper = CustomAllReduceHelper(size=8 << 20, timeout_ms=10000)  # the direct launcher's bound (the plugin's: 30 s)
+        # timeout_ms: the direct launcher's bound (the plugin's: 30 s).  max_workgroups: the ranks share ONE GPU here, and
+        # a workgroup that waits for its peers keeps its slot -- 8 ranks x 256 workgroups do not fit the chip together
+        # (measured: some ranks' workgroups never start and the waits run out), so the count per rank is bounded
+        helper = CustomAllReduceHelper(size=8 << 20, timeout_ms=10000, max_workgroups=max(32, 512 // world))
         say = (lambda m: print(f"[allreduce world {world}] {m}", flush=True)) if rank == 0 else (lambda m: None)
         # the last two: 1 MiB (256 workgroups of 4 KiB, the cfg4 M = 64 message) and 2 MiB per rank
         # incl. the cfg4 messages [M, 8192] bf16 for M = 1, 8, 64 (16 KB, 128 KB, 1 MB)
@@ -167,7 +170,7 @@ def _worker(rank, world, port, results):
         if ok and world == 2:
             # a late rank: rank 1 arrives 1.5 s after rank 0, whose waits are bounded to 0.3 s -> rank 0 gets NaN and
             # the timeout word, and refuses further all-reduces; rank 1 finds rank 0's data and flags in place
-            late = CustomAllReduceHelper(size=1 << 20, timeout_ms=300 if rank == 0 else 0)
+            late = CustomAllReduceHelper(size=1 << 20, timeout_ms=300 if rank == 0 else 0, max_workgroups=128)
             x = torch.full((4096,), float(rank + 1), dtype=torch.float16, device=dev)
             dist.barrier()
             if rank == 1:
