@@ -221,7 +221,10 @@ def bench_int8_gemm(dev, steps, m=4096, n=13824, k=5120):
                                        ("type_id", 1, 5)])
     out = torch.empty(m, n, dtype=torch.float16, device=dev)
     ins = [a, b, sa, sb]
-    _, dev_s = time_steps(lambda: plg.enqueue(ins, [out]), steps, 2, lambda: None)
+    plg.configure(ins)
+    ws_bytes = plg.get_workspace_size(ins, [out])      # the split-K-remainder kernel's partial tiles (TensorRT's scratch)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    _, dev_s = time_steps(lambda: plg.enqueue(ins, [out], ws), steps, 2, lambda: None)
     ops = 2.0 * m * n * k
     return {"m": m, "n": n, "k": k, "ms_per_call": dev_s / steps * 1e3, "TOPS": ops / (dev_s / steps) / 1e12,
             "frac_of_int8_peak": ops / (dev_s / steps) / 1e12 / INT8_PEAK_TOPS}

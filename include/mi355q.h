@@ -279,6 +279,19 @@ extern "C"
         const float* alphaCol, const float* alphaRow, void* C, int32_t out_type, int32_t m, int32_t n, int32_t k,
         void* stream);
 
+    /* The same with the runner's workspace arguments (int8_gemm.h:54-58 gemm(..., workspacePtr, workspaceBytes, stream),
+     * getWorkspaceSize(m, n, k) :63): the reference's CUTLASS kernels use it for serial split-k, here it holds the partial
+     * tiles of the persistent / stream-K kernel that shapes whose 256 x 256 tiles leave the last round of CUs part-filled
+     * take (cfg3: 864 tiles = 3.375 rounds).  mi355q_gemm8_workspace_size: bytes for this m, n, k (0 = the shape does
+     * not use one; at most 64 MiB); with a null / smaller workspace the call runs one tile per workgroup.  int8 results
+     * are bit-identical either way; fp8 sums its fp32 partial sums in a fixed order.  Workspace 256-byte aligned. */
+    size_t mi355q_gemm8_workspace_size(int32_t m, int32_t n, int32_t k);
+    mi355q_status mi355q_int8_gemm_ws(const int8_t* A, const int8_t* B, int32_t per_token, int32_t per_channel,
+        const float* alphaCol, const float* alphaRow, void* C, int32_t out_type, int32_t m, int32_t n, int32_t k,
+        void* workspace, size_t workspaceBytes, void* stream);
+    mi355q_status mi355q_fp8_gemm_ws(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C,
+        int32_t out_type, int32_t m, int32_t n, int32_t k, void* workspace, size_t workspaceBytes, void* stream);
+
     /* kernels/quantization.cu:118-127 invokePerTokenQuantization */
     mi355q_status mi355q_per_token_quantization(int8_t* dst, const void* src, int64_t numRows, int64_t numCols,
         float* scalePtr, int32_t src_type, void* stream);

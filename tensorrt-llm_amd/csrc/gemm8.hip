@@ -652,32 +652,44 @@ __global__ __launch_bounds__(512) void gemm8_phased_kernel(Gemm8Args g, int tile
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent / stream-K form of the phased kernel (round 3).  The phased kernel runs one 256 x 256
-// tile per workgroup and one workgroup per CU, so a problem of T tiles takes ceil(T / 256) rounds whatever T % 256 is:
-// cfg3 (4096 x 13824 x 5120) is 864 tiles = 3.375 rounds of work in 4 rounds of time (the round-2 remedy, a second
-// launch with smaller tiles for the last columns, took 107 us for 0.375 rounds).  Here `grid` workgroups stay resident:
+// Persistent / split-K-remainder form of the phased kernel (round 3).  The phased kernel runs one
+// 256 x 256 tile per workgroup and one workgroup per CU, so a problem of T tiles takes ceil(T / 256) rounds whatever
+// T % 256 is: cfg3 (4096 x 13824 x 5120) is 864 tiles = 3.375 rounds of work in 4 rounds of time (the round-2 remedy,
+// a second launch with smaller tiles for the last columns, took 107 us for 0.375 rounds).  Here `grid` workgroups
+// stay resident:
 //   * the first floor(T / grid) * grid tiles are walked one per workgroup and round with the phased loop (same XCD
 //     chunks and grouped rasterisation);
-//   * the K-tiles of the remaining R tiles form ONE sequence of R * nk iterations, cut into equal runs of `sk_iters`,
-//     one run per workgroup (the stream-K decomposition: every CU gets the same number of K-tiles).  A run that ends
-//     inside a tile leaves a partial accumulator: the workgroup stores its 256 x 256 image (fragment order, 16-byte
-//     write-through stores), drains, and raises its flag.  The workgroup that holds the tile's LAST K-tiles adds the
-//     images of the others to its registers and runs the epilogue.  int32 sums are exact in any order, so the
-//     SmoothQuant result is bit-identical to the one-pass kernel's; fp8 sums partial fp32 sums in a fixed order.
-// A finishing workgroup only ever waits for workgroups with a LOWER index, and those never wait for it: workgroups are
-// dispatched in index order, so what it waits for is running or done whatever else occupies the chip -- no deadlock,
-// no co-residency requirement.  Every workgroup first runs the segment it must hand over and finishes a tile last, so
-// the hand-over is ready long before it is asked for.  The wait is bounded all the same (8 s of s_memrealtime): on
-// expiry the tile is poisoned (NaN / INT_MIN).  Flags are arrival_ring words (zero at launch, put back to zero by the
-// consumer).  Requires m % 256 == 0, n % 256 == 0, k % 128 == 0.
+//   * each of the remaining R tiles is cut over K into s = floor(grid / R) equal pieces, one piece per workgroup, and
+//     these pieces are run FIRST, all together: the workgroups of piece p walk the same K range in step, like the tiles
+//     of a round, so what they stream is shared in the L2s.  A piece ends with its 256 x 256 accumulator image (fragment
+//     order) stored to the workspace with 16-byte write-through stores, a drain, and one count on an arrival word;
+//   * after its data-parallel tiles every workgroup takes a share of the 32 R "units" (8 KiB of an image: one value
+//     quad per thread): adds the s images of the tile and runs the epilogue on the sum.  int32 sums are exact in any
+//     order, so the SmoothQuant result is bit-identical to the one-pass kernel's; fp8 adds its s fp32 partial sums in
+//     piece order.
+// Two forms were built and measured before this one (tools/lab_sk.py): (1) the textbook stream-K cut -- R * nk K-tiles
+// in equal runs whatever the tile boundaries, the workgroup with a tile's last K-tiles adding the others' images --
+// exact, and SLOWER than one tile per workgroup (274 vs 251 us at cfg3 even with the hand-over removed): workgroups of
+// one tile row / column sit at different K positions, nothing they stream is shared in the L2 any more, and the
+// remainder phase asks HBM for 250 MB in the time of 15 K-tiles; (2) equal pieces, the last piece's workgroup starting
+// its accumulators from the others' images -- the hand-over pieces had to run before the data-parallel tiles and the
+// finishing pieces after, which puts a third of the workgroups half a tile out of step for the whole launch (no gain).
+// The images are written at the start of the launch and read a whole data-parallel phase later, so the wait below is
+// satisfied on arrival; nobody waits for a workgroup that has not already had its first turn on a CU -- no deadlock
+// however the workgroups are scheduled, provided all `grid` of them get a CU at all (grid <= 256 = the CUs; the wait is
+// bounded by 8 s of s_memrealtime all the same, then the remainder tiles are poisoned with NaN).  The two counting
+// words are arrival_ring words (zero at launch, put back to zero by the last workgroup to leave).
+// m % 256 == 0, n % 256 == 0, k % 128 == 0.
 struct SkArgs
 {
-    int grid;           // workgroups launched (<= 256; a multiple of 8 when dp_rounds > 0)
+    int grid;           // workgroups launched (<= 256, a multiple of 8)
     int dp_rounds;      // whole rounds of `grid` tiles
-    int sk_tiles;       // tiles after them, cut over K
-    int sk_iters;       // K-tiles per workgroup in the stream-K part
+    int sk_tiles;       // R: tiles after them
+    int sk_split;       // s: pieces per such tile (R * s <= grid)
+    int sk_iters;       // K-tiles per piece (the last piece takes what is left)
     uint32_t* partials; // [workgroup][256 * 256] accumulator images
-    uint32_t* flags;    // one word per workgroup, ARRIVAL_WORD_STRIDE apart
+    uint32_t* flags;    // two words, ARRIVAL_WORD_STRIDE apart: images stored | workgroups that have left
+    int abl;            // LAB build: 1 skip the unit pass, 2 the image stores, 4 the tiles' output stores (wrong results, timing only)
 };
 
 template <bool FP8>
@@ -706,19 +718,30 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(Gemm8Args g, int tiles_m,
     const int off_k0 = frow * TK + ((c0 ^ fsw) << 4), off_k1 = frow * TK + ((c1 ^ fsw) << 4);
     const int a_row0 = wr * 64 * TK;
     const int b_row0 = wc * 32 * TK;
-    const int em = lane & 15, en = (lane >> 4) * 4;
 
-    // this workgroup's run of the stream-K iteration space: tiles tA .. tB, from K-tile kA of tA to kB (exclusive) of tB
+    // piece b / R of remainder tile b % R for b < R * s, run first
     const int dp_tiles = sk.dp_rounds * sk.grid;
-    const int it0 = b * sk.sk_iters, it1 = min(it0 + sk.sk_iters, sk.sk_tiles * nk);
-    int nseg = 0, tA = 0, kA = 0, tB = 0, kB = 0;
-    if (it0 < it1)
+    const int R = sk.sk_tiles;
+    // pieces go to whole XCDs (workgroup b runs on XCD b % 8): the workgroups of an XCD stay in step with each other
+    // (they share tile panels in its L2) while XCDs with and without a piece end up half a tile apart, so not every
+    // CU of the chip stores its tile and fetches the next one's first K-tiles in the same microseconds
+    const int rho = (b & 7) * (sk.grid >> 3) + (b >> 3);
+    const int has_piece = rho < R * sk.sk_split ? 1 : 0;
+    const int nwork = has_piece + sk.dp_rounds;
+    // the XCD-chunk map of the phased kernel over the R tiles (workgroups b and b + 8 share an L2)
+    auto remainder_tile = [&](int o)
     {
-        tA = it0 / nk, kA = it0 - tA * nk;
-        tB = (it1 - 1) / nk, kB = it1 - tB * nk;
-        nseg = tB - tA + 1;
-    }
-    const int nwork = sk.dp_rounds + nseg;
+        const int q = R / 8, r = R % 8, x = o % 8;
+        return dp_tiles + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o / 8;
+    };
+    auto tile_origin = [&](int lin, size_t& m0, size_t& n0)
+    {
+        const int per_group = group_m * tiles_n;
+        const int first_tm = (lin / per_group) * group_m;
+        const int gsz = min(group_m, tiles_m - first_tm);
+        m0 = (size_t) (first_tm + (lin % per_group) % gsz) * 256;
+        n0 = (size_t) ((lin % per_group) / gsz) * 256;
+    };
 
 #define P8_BARRIER()                                                                                                   \
     do                                                                                                                 \
@@ -731,28 +754,32 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(Gemm8Args g, int tiles_m,
 #define P8_WAIT_VM6() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
 #define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+#pragma unroll 1
     for (int work = 0; work < nwork; ++work)
     {
         int lin, k0, k1;
-        if (work < sk.dp_rounds)
+        const int w = work - has_piece;
+        if (w >= 0)
         {
-            lin = (b & 7) * (dp_tiles >> 3) + work * (sk.grid >> 3) + (b >> 3); // an XCD walks its own chunk of tiles
+            lin = (b & 7) * (dp_tiles >> 3) + w * (sk.grid >> 3) + (b >> 3); // an XCD walks its own chunk of tiles
             k0 = 0, k1 = nk;
         }
         else
         {
-            const int t = tB - (work - sk.dp_rounds); // last tile of the run first: that one is handed over
-            lin = dp_tiles + t;
-            k0 = t == tA ? kA : 0;
-            k1 = t == tB ? kB : nk;
+            lin = remainder_tile(rho % R);
+            k0 = (rho / R) * sk.sk_iters;
+            k1 = min(nk, k0 + sk.sk_iters);
         }
-        const int per_group = group_m * tiles_n;
-        const int first_tm = (lin / per_group) * group_m;
-        const int gsz = min(group_m, tiles_m - first_tm);
-        const int tm = first_tm + (lin % per_group) % gsz, tn = (lin % per_group) / gsz;
-        const size_t m0 = (size_t) tm * 256, n0 = (size_t) tn * 256;
+        size_t m0, n0;
+        tile_origin(lin, m0, n0);
         const int nkt = k1 - k0;
 
+        acc_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = acc_t{0, 0, 0, 0};
         const uint8_t* usrc[4][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -775,13 +802,6 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(Gemm8Args g, int tiles_m,
             __builtin_amdgcn_global_load_lds(
                 (gbl_void_t*) (usrc[unit][1] + (size_t) t * TK), (lds_void_t*) (dst + 1024), 16, 0, 0);
         };
-
-        acc_t acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = acc_t{0, 0, 0, 0};
         i32x4_t fa[4][2], fb0[2][2], fb1[2][2], fb0n[2][2];
 
         auto read_a = [&](const uint8_t* unit_base)
@@ -887,81 +907,32 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(Gemm8Args g, int tiles_m,
             P8_BARRIER();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-        if (k1 < nk)
+        if (w < 0)
         {
-            // hand the partial tile over: image of workgroup b, value (i, j) of thread tid at ((i * 4 + j) * 512 + tid) * 16
+            // a piece: image rho, value (i, j) of thread tid at ((i * 4 + j) * 512 + tid) * 16
             const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
-                (void*) (reinterpret_cast<uint8_t*>(sk.partials) + (size_t) b * IMAGE_BYTES), 0, (int) IMAGE_BYTES, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(u32x4_t, acc[i][j]), img, ((i * 4 + j) * 512 + tid) * 16, 0, 16 /* sc1 */);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave, before the barrier the signalling lane passes
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store((gu32_t*) (sk.flags + (size_t) b * ARRIVAL_WORD_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue; // (the barrier above also released the LDS)
-        }
-        if (k0 > 0)
-        {
-            // the tile's last K-tiles are here: add what the workgroups before this one left
-            const int first = ((lin - dp_tiles) * nk) / sk.sk_iters;
-            if (tid == 0)
-            {
-                int ok = 1;
-                for (int c = first; c < b; ++c)
-                {
-                    gu32_t* f = (gu32_t*) (sk.flags + (size_t) c * ARRIVAL_WORD_STRIDE);
-                    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                    {
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > 800000000ull) // 8 s at 100 MHz
-                        {
-                            ok = 0;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // clean for the next launch
-                }
-                sk_ok = ok;
-            }
-            __syncthreads();
-            const bool ok = sk_ok != 0;
-            for (int c = first; c < b; ++c)
-            {
-                const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*) (reinterpret_cast<uint8_t*>(sk.partials) + (size_t) c * IMAGE_BYTES), 0, (int) IMAGE_BYTES, 0x00020000);
-#pragma unroll
-                for (int half = 0; half < 2; ++half)
-                {
-                    u32x4_t v[16]; // 16 loads in flight (the fragment registers are free here)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        v[q] = __builtin_amdgcn_raw_buffer_load_b128(img, ((half * 16 + q) * 512 + tid) * 16, 0, 16 /* sc1 */);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        acc[half * 4 + q / 4][q % 4] += __builtin_bit_cast(acc_t, v[q]);
-                }
-            }
-            if (!ok)
+                (void*) (reinterpret_cast<uint8_t*>(sk.partials) + (size_t) rho * IMAGE_BYTES), 0, (int) IMAGE_BYTES, 0x00020000);
+            if (!(sk.abl & 2))
             {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                    {
-                        if constexpr (FP8)
-                            acc[i][j] = acc_t{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                        else
-                            acc[i][j] = acc_t{INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
-                    }
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(u32x4_t, acc[i][j]), img, ((i * 4 + j) * 512 + tid) * 16, 0, 16 /* sc1 */);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave, before the barrier the counting lane passes
+            __syncthreads();
+            if (tid == 0)
+                __builtin_amdgcn_atomic_inc32((gu32_t*) sk.flags, 0xffffffffu, __ATOMIC_RELAXED, "agent");
+            continue; // (the barrier above also released the LDS)
         }
 
-        // epilogue (gemm8_phased_kernel's)
+        // epilogue (gemm8_phased_kernel's).  The lane id goes through an empty asm: hoisted out of the work loop the
+        // epilogue's lane addresses would live (spilled) across the K loop
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int em = elane & 15, en = (elane >> 4) * 4;
         float sr[8], sc[4][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -983,11 +954,89 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(Gemm8Args g, int tiles_m,
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         v[r] = (float) acc[i][j][r] * (sc[j][r] * sr[i]);
-                    gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
+                    if (!(sk.abl & 4))
+                        gemm8_store4<decltype(out)::value>(g.C, row * g.ldc + col, v);
                 }
             }
         });
-        __syncthreads(); // the LDS (and sk_ok) are free for the next tile
+        __syncthreads(); // the LDS is free for the next tile
+    }
+
+    // ---- the unit pass: sum the pieces' images and run the epilogue on the sums, 8 KiB of a tile per workgroup and step
+    if (tid == 0)
+    {
+        int good = 1;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load((gu32_t*) sk.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t) (R * sk.sk_split))
+        {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 800000000ull) // 8 s at 100 MHz
+            {
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sk_ok = good;
+    }
+    __syncthreads();
+    {
+        const float poison = sk_ok ? 1.f : __builtin_nanf(""); // images that never came: NaN in the floating-point outputs
+        const int em = lane & 15, en = (lane >> 4) * 4;
+        const int units = (sk.abl & 1) ? 0 : R * 32;
+        constexpr int UB = 4; // units in flight per thread
+        for (int u0 = b; u0 < units; u0 += UB * sk.grid)
+        {
+            u32x4_t v[UB][4];
+            float sr[UB], sc[UB][4];
+            size_t dst[UB];
+#pragma unroll
+            for (int x = 0; x < UB; ++x)
+            {
+                const int u = min(u0 + x * sk.grid, units - 1); // past the end: the last unit again, not stored
+                const int o = u >> 5, q = u & 31;
+                size_t m0, n0;
+                tile_origin(remainder_tile(o), m0, n0);
+                const size_t row = m0 + wr * 128 + (q >> 2) * 16 + em, col = n0 + wc * 64 + (q & 3) * 16 + en;
+                dst[x] = row * g.ldc + col;
+                sr[x] = g.alpha_row[g.per_token ? row : 0] * poison;
+                gemm8_col_scales(g, col, sc[x]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                {
+                    const int pp = min(p, sk.sk_split - 1);
+                    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*) (reinterpret_cast<uint8_t*>(sk.partials) + (size_t) (pp * R + o) * IMAGE_BYTES), 0,
+                        p < sk.sk_split ? (int) IMAGE_BYTES : 0, 0x00020000); // pieces that do not exist read as zero
+                    v[x][p] = __builtin_amdgcn_raw_buffer_load_b128(img, (q * 512 + tid) * 16, 0, 16 /* sc1 */);
+                }
+            }
+            gemm8_dispatch_out(g.out_type, [&](auto out)
+            {
+#pragma unroll
+                for (int x = 0; x < UB; ++x)
+                {
+                    acc_t a = __builtin_bit_cast(acc_t, v[x][0]);
+#pragma unroll
+                    for (int p = 1; p < 4; ++p)
+                        a += __builtin_bit_cast(acc_t, v[x][p]);
+                    float r4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        r4[r] = (float) a[r] * (sc[x][r] * sr[x]);
+                    if (u0 + x * sk.grid < units)
+                        gemm8_store4<decltype(out)::value>(g.C, dst[x], r4);
+                }
+            });
+        }
+    }
+    // leave: the last workgroup out puts both words back to zero for the next launch
+    __syncthreads();
+    if (tid == 0)
+    {
+        const uint32_t seen = __builtin_amdgcn_atomic_inc32(
+            (gu32_t*) (sk.flags + ARRIVAL_WORD_STRIDE), (uint32_t) (sk.grid - 1), __ATOMIC_RELAXED, "agent");
+        if (seen == (uint32_t) (sk.grid - 1))
+            __hip_atomic_store((gu32_t*) sk.flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef P8_BARRIER
 #undef P8_WAIT_VM8
@@ -1386,6 +1435,75 @@ void launch_phased(const Gemm8Args& g, hipStream_t stream)
         g.n / 256, group_m);
 }
 
+// ---- stream-K plan: whole rounds of 256 tiles data-parallel, the remaining tiles cut over K (gemm8_sk_kernel)
+struct SkPlan
+{
+    bool use;
+    int grid, dp_rounds, sk_tiles, sk_split, sk_iters, sk_workgroups;
+};
+constexpr int SK_GRID = 256;                              // one workgroup per CU
+constexpr size_t SK_IMAGE_BYTES = (size_t) 256 * 256 * 4; // one partial accumulator tile
+
+SkPlan sk_plan(int m, int n, int k)
+{
+    SkPlan p{};
+    if (m <= 0 || m % 256 || n % 256 || k % 128)
+        return p;
+    const int tiles = (m / 256) * (n / 256), nk = k / 128;
+    p.dp_rounds = tiles / SK_GRID;
+    p.sk_tiles = tiles % SK_GRID;
+    if (p.sk_tiles == 0)
+        return p; // whole rounds: the plain phased kernel
+    // pieces per remainder tile: as many as fill the CUs, at most 4 (the unit pass holds 4 image quads per unit), at
+    // least 4 K-tiles per piece (a piece pays a pipeline fill)
+    int s = std::min({SK_GRID / p.sk_tiles, 4, std::max(1, nk / 4)});
+    while (s > 1 && (s - 1) * ((nk + s - 1) / s) >= nk)
+        --s; // every piece must hold at least one K-tile
+    if (s <= 1)
+        return p; // nothing to cut: the remainder is a round of its own either way
+    p.sk_split = s;
+    p.sk_iters = (nk + s - 1) / s;
+    p.sk_workgroups = p.sk_tiles * s;
+    p.grid = p.dp_rounds > 0 ? SK_GRID : (p.sk_workgroups + 7) / 8 * 8;
+    // Is it worth it?  Measured on MI355X (tools/lab_sk.py, interleaved A/B, us): a K-tile of the phased loop 1.64 with
+    // the whole chip busy (1.3 with less than a round of tiles), a tile's output stores 8.5 (all CUs store in the same
+    // microseconds: 32 MB at the HBM write rate), the images + unit pass 12 + 0.03 per image, and 15 of margin (the
+    // model was that much too kind to the cut at fp8 4096 x 14336 x 4096).  Against it: the remainder as one more round
+    // of whole tiles, or as half-width tiles where the launcher would use them (cost of the 256 x 128 kernel: 0.8 of
+    // the phased kernel's rate).  cfg3: 4096 x 5120 x 13824 (64 remainder tiles, 4 pieces of 27 K-tiles) takes the cut,
+    // 267 -> 241 us; 4096 x 13824 x 5120 (96 tiles, 2 pieces of 20) does not: its remainder as 192 half-width tiles
+    // costs 40 us, the cut 55.
+    const double iter = p.dp_rounds > 0 ? 1.64 : 1.3, stores = 8.5;
+    const double cut = p.sk_iters * iter + stores + 12.0 + 0.03 * p.sk_workgroups + 15.0;
+    double plain = nk * iter + stores;
+    if (2 * p.sk_tiles <= SK_GRID)
+        plain = std::min(plain, (nk * iter + stores) * 0.5 / 0.8 + 3.0);
+    p.use = cut < plain;
+    return p;
+}
+
+template <bool FP8>
+void launch_sk(const Gemm8Args& g, const SkPlan& p, void* workspace, hipStream_t stream)
+{
+    static const int group_m = lab_env("MI355Q_GEMM8_GROUP_M") ? std::max(1, atoi(lab_env("MI355Q_GEMM8_GROUP_M"))) : 4;
+    SkArgs sk{};
+    sk.grid = p.grid;
+    sk.dp_rounds = p.dp_rounds;
+    sk.sk_tiles = p.sk_tiles;
+    sk.sk_split = p.sk_split;
+    sk.sk_iters = p.sk_iters;
+    sk.partials = static_cast<uint32_t*>(workspace);
+    sk.flags = arrival_lines(2, stream);
+    sk.abl = lab_env("MI355Q_SK_ABL") ? atoi(lab_env("MI355Q_SK_ABL")) : 0;
+    hipLaunchKernelGGL(gemm8_sk_kernel<FP8>, dim3(p.grid), dim3(512), 0, stream, g, g.m / 256, g.n / 256, group_m, sk);
+}
+
+bool sk_workspace_ok(const SkPlan& p, const void* workspace, size_t workspace_bytes)
+{
+    return p.use && workspace && ((uintptr_t) workspace & 255) == 0 && workspace_bytes >= (size_t) p.sk_workgroups * SK_IMAGE_BYTES
+        && !lab_env("MI355Q_GEMM8_NO_SK");
+}
+
 // columns [n_begin, n_begin + n_count) of the problem as a problem of its own
 Gemm8Args column_slice(const Gemm8Args& g, int n_begin, int n_count)
 {
@@ -1444,11 +1562,17 @@ void launch_tile(int c, const Gemm8Args& g, hipStream_t stream)
 // tiles fill whole rounds of the 256 CUs plus a remainder range run with whichever shape fills the
 // chip best (e.g. 4096 x 13824: 864 tiles = 3.375 rounds -> 768 tiles in 3 full rounds + 96 tiles'
 // worth of columns as 192 256 x 128 blocks).
-bool try_launch_big_int8(const Gemm8Args& g, hipStream_t stream)
+bool try_launch_big_int8(const Gemm8Args& g, void* workspace, size_t workspace_bytes, hipStream_t stream)
 {
     if (g.k % 128 != 0 || g.m % 128 != 0 || g.n % 128 != 0)
         return false;
     const char* force = lab_env("MI355Q_GEMM8_TILE"); // measurement override: 0..2 single shape, 3 = old 256^2 kernel
+    const SkPlan sk = sk_plan(g.m, g.n, g.k);
+    if (!force && sk_workspace_ok(sk, workspace, workspace_bytes))
+    {
+        launch_sk<false>(g, sk, workspace, stream); // a part-filled last round: persistent workgroups, stream-K remainder
+        return true;
+    }
     if (force && force[0] >= '0' && force[0] <= '2' && tile_cost(TILES[force[0] - '0'], g.m, g.n) < 1e29)
     {
         launch_tile(force[0] - '0', g, stream);
@@ -1642,8 +1766,21 @@ void check_gemm(int m, int n, int k, const void* A, const void* B, const void* C
 
 } // namespace
 
+// bytes of workspace with which int8_gemm / fp8_gemm run the stream-K form (0: the shape does not take it).  With less
+// (or none) they fall back to one tile per workgroup.
+size_t gemm8_workspace_size(int m, int n, int k)
+{
+    const SkPlan p = sk_plan(m, n, k);
+    return p.use ? (size_t) p.sk_workgroups * SK_IMAGE_BYTES : 0; // one image per piece
+}
+size_t gemm8_workspace_size_max(int n, int k)
+{
+    return (n > 0 && k > 0 && n % 256 == 0 && k % 128 == 0) ? (size_t) SK_GRID * SK_IMAGE_BYTES : 0; // R s <= 256
+}
+
 void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel, const float* alphaCol,
-    const float* alphaRow, void* C, int out_type, int m, int n, int k, hipStream_t stream)
+    const float* alphaRow, void* C, int out_type, int m, int n, int k, void* workspace, size_t workspace_bytes,
+    hipStream_t stream)
 {
     if (m == 0)
         return;
@@ -1656,7 +1793,7 @@ void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel,
         return;
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, alphaCol, alphaRow,
         per_token, per_channel, m, n, k, out_type, n};
-    if (!try_launch_big_int8(g, stream))
+    if (!try_launch_big_int8(g, workspace, workspace_bytes, stream))
     {
         dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM);
         hipLaunchKernelGGL((gemm8_kernel<false>), grid, dim3(256), 0, stream, g);
@@ -1665,7 +1802,7 @@ void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel,
 }
 
 void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C, int out_type, int m,
-    int n, int k, hipStream_t stream)
+    int n, int k, void* workspace, size_t workspace_bytes, hipStream_t stream)
 {
     if (m == 0)
         return;
@@ -1678,7 +1815,10 @@ void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* sc
     // per-tensor scales: alpha_row = scaleA[0], alpha_col = scaleB[0]
     Gemm8Args g{reinterpret_cast<const uint8_t*>(A), reinterpret_cast<const uint8_t*>(B), C, scaleB, scaleA, 0, 0, m,
         n, k, out_type, n};
-    if (m % 256 == 0 && n % 256 == 0 && k % 128 == 0 && !lab_env("MI355Q_FP8_SMALL_TILE"))
+    const SkPlan sk = sk_plan(m, n, k);
+    if (sk_workspace_ok(sk, workspace, workspace_bytes) && !lab_env("MI355Q_FP8_SMALL_TILE"))
+        launch_sk<true>(g, sk, workspace, stream);
+    else if (m % 256 == 0 && n % 256 == 0 && k % 128 == 0 && !lab_env("MI355Q_FP8_SMALL_TILE"))
         launch_phased<true>(g, stream);
     else
     {

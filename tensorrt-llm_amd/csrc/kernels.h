@@ -69,10 +69,15 @@ void apply_per_channel_scale_fp8(
 void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stream);
 
 // gemm8.hip
+// workspace: gemm8_workspace_size(m, n, k) bytes let shapes whose 256 x 256 tiles do not fill whole rounds of the CUs
+// run the persistent / stream-K kernel; null or smaller = one tile per workgroup (same results for int8)
+size_t gemm8_workspace_size(int m, int n, int k);
+size_t gemm8_workspace_size_max(int n, int k); // bound over every m
 void int8_gemm(const int8_t* A, const int8_t* B, int per_token, int per_channel, const float* alphaCol,
-    const float* alphaRow, void* C, int out_type, int m, int n, int k, hipStream_t stream);
+    const float* alphaRow, void* C, int out_type, int m, int n, int k, void* workspace, size_t workspace_bytes,
+    hipStream_t stream);
 void fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C, int out_type, int m,
-    int n, int k, hipStream_t stream);
+    int n, int k, void* workspace, size_t workspace_bytes, hipStream_t stream);
 void per_token_quantization(
     int8_t* dst, const void* src, int64_t rows, int64_t cols, float* scales, int src_type, hipStream_t stream);
 void quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols, int src_type, int mode,

@@ -432,15 +432,23 @@ struct SmoothQuantGemmPlugin : PluginBase
         if (!mDims.isInitialized())
             mDims = {rows_of(in[0].min), rows_of(in[0].max), in[1].max.d[0], in[0].max.d[in[0].max.nbDims - 1]};
     }
+    // :200-203 (m_workspaceMaxSize = the runner's split-k workspace): here the partial tiles of the stream-K kernel, a
+    // bound that holds for every m the profile allows
+    size_t workspaceSize(const mi355q_tensor_desc* in, int nbIn, const mi355q_tensor_desc*, int) const override
+    {
+        if (nbIn < 2 || in[0].dims.nbDims < 1)
+            return 0;
+        return gemm8_workspace_size_max(in[1].dims.d[0], in[0].dims.d[in[0].dims.nbDims - 1]);
+    }
     void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
-        void* const* outputs, void*, hipStream_t stream) override // :220-247
+        void* const* outputs, void* workspace, hipStream_t stream) override // :220-247
     {
         const int m = rows_of(inDesc[0].dims);
         const int n = inDesc[1].dims.d[0];
         const int k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
         int8_gemm(static_cast<const int8_t*>(inputs[0]), static_cast<const int8_t*>(inputs[1]), perToken(),
             perChannel(), static_cast<const float*>(inputs[3]), static_cast<const float*>(inputs[2]), outputs[0], mType,
-            m, n, k, stream);
+            m, n, k, workspace, workspace ? gemm8_workspace_size_max(n, k) : 0, stream);
     }
     size_t serializationSize() const override // :288-296
     {
@@ -1061,14 +1069,20 @@ struct Fp8GemmPlugin : PluginBase
     {
         return mType;
     }
+    size_t workspaceSize(const mi355q_tensor_desc* in, int nbIn, const mi355q_tensor_desc*, int) const override
+    {
+        if (nbIn < 2 || in[0].dims.nbDims < 1)
+            return 0;
+        return gemm8_workspace_size_max(in[1].dims.d[0], in[0].dims.d[in[0].dims.nbDims - 1]);
+    }
     void enqueue(const mi355q_tensor_desc* inDesc, const mi355q_tensor_desc*, const void* const* inputs,
-        void* const* outputs, void*, hipStream_t stream) override
+        void* const* outputs, void* workspace, hipStream_t stream) override
     {
         const int m = rows_of(inDesc[0].dims);
         const int n = inDesc[1].dims.d[0];
         const int k = inDesc[0].dims.d[inDesc[0].dims.nbDims - 1];
         fp8_gemm(inputs[0], inputs[1], static_cast<const float*>(inputs[2]), static_cast<const float*>(inputs[3]),
-            outputs[0], mType, m, n, k, stream);
+            outputs[0], mType, m, n, k, workspace, workspace ? gemm8_workspace_size_max(n, k) : 0, stream);
     }
     size_t serializationSize() const override
     {
@@ -2045,7 +2059,35 @@ extern "C"
         return guarded(
             [&]
             {
-                int8_gemm(A, B, per_token, per_channel, alphaCol, alphaRow, C, out_type, m, n, k,
+                int8_gemm(A, B, per_token, per_channel, alphaCol, alphaRow, C, out_type, m, n, k, nullptr, 0,
+                    static_cast<hipStream_t>(stream));
+            });
+    }
+
+    size_t mi355q_gemm8_workspace_size(int32_t m, int32_t n, int32_t k)
+    {
+        return gemm8_workspace_size(m, n, k);
+    }
+
+    mi355q_status mi355q_int8_gemm_ws(const int8_t* A, const int8_t* B, int32_t per_token, int32_t per_channel,
+        const float* alphaCol, const float* alphaRow, void* C, int32_t out_type, int32_t m, int32_t n, int32_t k,
+        void* workspace, size_t workspaceBytes, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                int8_gemm(A, B, per_token, per_channel, alphaCol, alphaRow, C, out_type, m, n, k, workspace,
+                    workspaceBytes, static_cast<hipStream_t>(stream));
+            });
+    }
+
+    mi355q_status mi355q_fp8_gemm_ws(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C,
+        int32_t out_type, int32_t m, int32_t n, int32_t k, void* workspace, size_t workspaceBytes, void* stream)
+    {
+        return guarded(
+            [&]
+            {
+                fp8_gemm(A, B, scaleA, scaleB, C, out_type, m, n, k, workspace, workspaceBytes,
                     static_cast<hipStream_t>(stream));
             });
     }
@@ -2061,7 +2103,7 @@ extern "C"
     mi355q_status mi355q_fp8_gemm(const void* A, const void* B, const float* scaleA, const float* scaleB, void* C,
         int32_t out_type, int32_t m, int32_t n, int32_t k, void* stream)
     {
-        return guarded([&] { fp8_gemm(A, B, scaleA, scaleB, C, out_type, m, n, k, static_cast<hipStream_t>(stream)); });
+        return guarded([&] { fp8_gemm(A, B, scaleA, scaleB, C, out_type, m, n, k, nullptr, 0, static_cast<hipStream_t>(stream)); });
     }
 
     mi355q_status mi355q_quantize_e4m3(void* dst, float* scales, const void* src, int64_t rows, int64_t cols,

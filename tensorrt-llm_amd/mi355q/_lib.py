@@ -202,6 +202,9 @@ SYMBOLS = {
     "mi355q_rms_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mi355q_layer_norm": (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "mi355q_fp8_gemm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_gemm8_workspace_size": (C.c_size_t, [_i32, _i32, _i32]),
+    "mi355q_int8_gemm_ws": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, C.c_size_t, _vp]),
+    "mi355q_fp8_gemm_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, C.c_size_t, _vp]),
     "mi355q_quantize_e4m3": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_moe_gemm_bias_act": (_i32, [C.POINTER(MoeGemmParams), _vp]),
     "mi355q_moe_workspace_size": (_sz, [C.POINTER(MoeParams)]),
