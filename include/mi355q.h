@@ -392,6 +392,16 @@ extern "C"
         /* ALiBi (position_embedding_type 3 / 4; decoderMaskedMultiheadAttentionTemplate.h:1891-1895, :2026): act_type
          * [num_heads] slopes, score += slope[h] * (t - tlength); NULL otherwise */
         const void* alibi_slopes;
+        /* position_shift_enabled (StreamingLLM; Multihead_attention_params::position_shift_enabled,
+         * decoderMaskedMultiheadAttention.h, POS_SHIFT of decoderMaskedMultiheadAttentionTemplate.h:1500, 1745-1752,
+         * 1918-1927, 2065, 2386; invokeShiftKCache, unfusedAttentionKernels.cu:1776-1947, called from
+         * gptAttentionCommon.cpp:1276-1290): the K cache holds keys WITHOUT the position embedding; every step the live
+         * keys -- the sink tokens and the last window - sink tokens -- are rotated to their position INSIDE the cache
+         * (0 .. kv length - 1 in age order), the query and the new key to position min(kv length, window), and the new
+         * key is stored un-rotated.  RoPE types only; 16-bit caches, beam width 1.  Needs the larger workspace
+         * mi355q_decode_attention_workspace_size reports (the rotated keys of the step: the reference's
+         * shift_k_cache, :1260-1262). */
+        int32_t position_shift_enabled;
     } mi355q_decode_attention_params;
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
     mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);
@@ -453,6 +463,10 @@ extern "C"
         /* ALiBi (position_embedding_type 3 / 4): T [num_heads] slopes, score += slope[h] * (t - a)
          * (unfusedAttentionKernels.cu:212-218); NULL otherwise */
         const void* alibi_slopes;
+        /* position_shift_enabled: the attention of this call is unchanged, but K goes to the cache WITHOUT the position
+         * embedding (k_to_cache = POS_SHIFT ? k_wo_pos : k, unfusedAttentionKernels_2_template.h:284-347), for
+         * generation steps with mi355q_decode_attention_params.position_shift_enabled */
+        int32_t position_shift_enabled;
     } mi355q_context_attention_params;
     size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params);
     mi355q_status mi355q_context_attention(const mi355q_context_attention_params* params, void* stream);

@@ -567,7 +567,7 @@ class CyclicMap:
 
 def decode_attention_slots(qkv, slots, seq_lens, num_heads, num_kv_heads, head_dim, cmap, q_scaling=1.0, rope=None,
                            rot_dim=0, rope_base=10000.0, rope_scale=1.0, kv_scale_orig_quant=1.0,
-                           kv_scale_quant_orig=1.0, beam_width=1, cache_indir=None, input_lengths=None):
+                           kv_scale_quant_orig=1.0, beam_width=1, cache_indir=None, input_lengths=None, pos_shift=False):
     """decode_attention over an explicit slot space, with the reference's cyclic / sink addressing and beams
     (decoderMaskedMultiheadAttentionTemplate.h, POS_SHIFT = false):
       * slots: torch [batch_beam, 2, Hkv, capacity, Dh] in the cache dtype -- slot s of a sequence, however the
@@ -581,7 +581,16 @@ def decode_attention_slots(qkv, slots, seq_lens, num_heads, num_kv_heads, head_d
       * beams: batch_idx = b // beam_width (:1611); slot t < beam0_context_length is read from row
         batch_idx * beam_width (:1929), later slots from row batch_idx * beam_width + cache_indir[b][t] (:2076, :2441);
         beam0_context_length = 0 once tlength > window, else input_lengths[b] (:1497-1498).
+    pos_shift (POS_SHIFT = true; StreamingLLM): the K cache holds keys WITHOUT position embedding.
+      * invokeShiftKCache (unfusedAttentionKernels.cu:1776-1947) rotates, before the step, the key at window position x
+        -- token_idx = x for the sink tokens, else cyclic_k_cache_start_idx + x - sink with the start = sink
+        (tlength <= window) or sink + tlength - window (:1790-1795) -- to position x (token_pos_idx, :1797) and stores
+        it in T (:1938-1941); the attention reads those keys (the same tokens: Template.h:1918-1927) and V from the
+        tokens' cache slots (:2386-2395);
+      * q and the new k are rotated to current_pos_idx = kv_loop_length (:1500); the cache receives k_wo_pos, the new
+        key with bias and without rotation (:1745-1752, 2216-2233).
     Same arithmetic as decode_attention otherwise.  Returns out [batch_beam, Hq * Dh] in T."""
+    assert not (pos_shift and (beam_width > 1 or rope is None))
     T = qkv.dtype
     B = qkv.shape[0]
     Hq, Hkv, D = num_heads, num_kv_heads, head_dim
@@ -596,11 +605,13 @@ def decode_attention_slots(qkv, slots, seq_lens, num_heads, num_kv_heads, head_d
         q = x[b, :Hq * D].reshape(Hq, D).numpy().copy()
         k = x[b, Hq * D:(Hq + Hkv) * D].reshape(Hkv, D).numpy().copy()
         v = x[b, (Hq + Hkv) * D:].reshape(Hkv, D).numpy().copy()
+        k_raw = k.copy()
         if rope is not None:
+            pos = kv_len if pos_shift else tl
             for h in range(Hq):
-                q[h] = apply_rope(q[h], tl, rot_dim, rope, rope_base, rope_scale)
+                q[h] = apply_rope(q[h], pos, rot_dim, rope, rope_base, rope_scale)
             for h in range(Hkv):
-                k[h] = apply_rope(k[h], tl, rot_dim, rope, rope_base, rope_scale)
+                k[h] = apply_rope(k[h], pos, rot_dim, rope, rope_base, rope_scale)
             q = torch.from_numpy(q).to(T).float().numpy()
             k = torch.from_numpy(k).to(T).float().numpy()
         rows = torch.full((kv_len,), b, dtype=torch.long)
@@ -611,8 +622,15 @@ def decode_attention_slots(qkv, slots, seq_lens, num_heads, num_kv_heads, head_d
             rows = base + torch.where(t < ctx0, torch.zeros_like(t), cache_indir[b, :kv_len].long())
         for hk in range(Hkv):
             idx = torch.arange(kv_len)
+            if pos_shift:
+                start = cmap.sink if tl <= cmap.window else cmap.sink + tl - cmap.window
+                idx = torch.tensor([cmap.slot(xx if xx < cmap.sink else start + xx - cmap.sink) for xx in range(kv_len)],
+                                   dtype=torch.long)
             kc = slots[rows, 0, hk, idx].float() * kv_scale_quant_orig
             vc = slots[rows, 1, hk, idx].float() * kv_scale_quant_orig
+            if pos_shift and kv_len:
+                kc = torch.from_numpy(np.stack([apply_rope(kc[xx].numpy(), xx, rot_dim, rope, rope_base, rope_scale)
+                                                for xx in range(kv_len)])).to(T).float()
             kk = torch.cat([kc, torch.from_numpy(k[hk:hk + 1])], 0).double()
             vv = torch.cat([vc, torch.from_numpy(v[hk:hk + 1])], 0).double()
             for g in range(grp):
@@ -621,7 +639,7 @@ def decode_attention_slots(qkv, slots, seq_lens, num_heads, num_kv_heads, head_d
                 p = torch.exp(logits - logits.max())
                 o = (p.double() @ vv).float() / (p.sum() + 1e-6)
                 out[b, h * D:(h + 1) * D] = o
-            writes.append((b, hk, cmap.slot(tl), quantize_kv(torch.from_numpy(k[hk]).to(T), slots.dtype, kv_scale_orig_quant),
+            writes.append((b, hk, cmap.slot(tl), quantize_kv(torch.from_numpy((k_raw if pos_shift else k)[hk]).to(T), slots.dtype, kv_scale_orig_quant),
                            quantize_kv(torch.from_numpy(v[hk]).to(T), slots.dtype, kv_scale_orig_quant)))
     for b, hk, s_, kq, vq in writes:  # all rows read before any is written (other beams read this row's slots)
         slots[b, 0, hk, s_] = kq
@@ -667,7 +685,7 @@ def apply_rope_rows(x, positions, rot_dim, kind, base=10000.0, scale=1.0):
 
 def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_dim, cache=None, q_scaling=1.0,
                       rope=None, rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None,
-                      kv_scale_orig_quant=1.0, past_lens=None, window=None, cmap=None, alibi_slopes=None):
+                      kv_scale_orig_quant=1.0, past_lens=None, window=None, cmap=None, alibi_slopes=None, pos_shift=False):
     """The context phase of GPTAttention (gptAttentionCommon.cpp:641-1133 enqueueContext), restated:
       * per input token: bias add in T, RoPE at the token's position in its sequence, rounded to T
         (invokeApplyBiasRopeUpdateKVCache / invokeAddFusedQKVBiasTranspose, unfusedAttentionKernels.cu);
@@ -683,7 +701,9 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
       * window (cyclic_attention_window_size): key t is visible to the query at position a iff a - window <= t <= a
         (gptKernels.cu:174-177); cmap (CyclicMap): the append keeps the sink tokens and the last window - sink tokens, at
         their cyclic slots (unfusedAttentionKernels_2_template.h:336-340);
-      * alibi_slopes [Hq] in T: score += slope[h] * (t - a) (unfusedAttentionKernels.cu:212-218).
+      * alibi_slopes [Hq] in T: score += slope[h] * (t - a) (unfusedAttentionKernels.cu:212-218);
+      * pos_shift (position_shift_enabled): the attention is unchanged, the cache receives K without the rotation
+        (k_to_cache = POS_SHIFT ? k_wo_pos : k, unfusedAttentionKernels_2_template.h:284-347).
     qkv_rows: list of torch [len_b, (Hq+2Hkv)*Dh] in T, one per sequence.  Returns a list of [len_b, Hq*Dh] in T.
     Tolerance parity like decode_attention (the reference rounds P to T before P.V).  No test of the reference covers
     chunked context, the sliding window or ALiBi in the context phase: those three are "parity unpinned"."""
@@ -702,6 +722,7 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
         past = 0 if past_lens is None else int(past_lens[b])
         kv_len = past + S
         pos = past + np.arange(S)
+        k_wo_pos = torch.from_numpy(x[:, Hq:Hq + Hkv].copy())   # bias added, rounded to T, not rotated
         if rope is not None:
             x[:, :Hq + Hkv] = apply_rope_rows(x[:, :Hq + Hkv], pos, rot_dim, rope, rope_base, rope_scale)
             x = torch.from_numpy(x).to(T).float().numpy()
@@ -716,7 +737,8 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
                         if not (a < cmap.sink or a >= max(kv_len - cmap.window + cmap.sink, cmap.sink)):
                             continue
                         slot = cmap.slot(a)
-                    cache.write(b, 0, hk, slot, quantize_kv(k[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
+                    k_to_cache = k_wo_pos[t, hk] if pos_shift else k[t, hk].float()
+                    cache.write(b, 0, hk, slot, quantize_kv(k_to_cache.to(T), cache.dtype, kv_scale_orig_quant))
                     cache.write(b, 1, hk, slot, quantize_kv(v[t, hk].float().to(T), cache.dtype, kv_scale_orig_quant))
         if past > 0:  # every key of the sequence, as the cache holds it
             assert cache is not None and cache.dtype == T

@@ -96,6 +96,8 @@ struct CtxArgs
     int kv_window, sink, bubble, cyc_len; // cache slot map of the append (kvCacheUtils.h:71-117); identity without a window
     const uint16_t* alibi_slopes;         // T [Hq] or null: score += slope[h] * (t - a)
     int dh_pad; // row length of `proc`: head_size, or the 64 / 128 it is padded to (zeros) for the attention kernel
+    int raw_k_cache; // POS_SHIFT: K goes to the cache without the position embedding (k_wo_pos,
+                     // unfusedAttentionKernels_2_template.h:284-347); generic prepare kernel only
 };
 
 __device__ __forceinline__ int ctx_kv_slot(const CtxArgs& p, int t)
@@ -165,6 +167,13 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
     const int half = p.rot_dim >> 1;
     const int past = ctx_past(p, b, len);
     const int pos = past + s;
+    float* k_raw = cs_tab + p.rot_dim; // [Hkv * D], POS_SHIFT only: the keys before the rotation
+    if (p.raw_k_cache)
+    {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Hkv * D; i += 256)
+            k_raw[i] = xs[Hq * D + i];
+    }
     if (rope && (int) threadIdx.x < half) // the angles only depend on (position, pair index): one table per token
     {
         const int j = threadIdx.x;
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256) void ctx_prepare_kernel(CtxArgs p)
         {
             const int e4 = 4 * i;
             const int kv = e4 / (Hkv * D), rem = e4 % (Hkv * D), hk = rem / D, d = rem % D;
-            const float* x = xs + (Hq + kv * Hkv + hk) * D + d;
+            const float* x = (p.raw_k_cache && kv == 0) ? k_raw + hk * D + d : xs + (Hq + kv * Hkv + hk) * D + d;
             const size_t e = ((size_t) hk * p.head_tokens + tin) * D + d;
             char* base = ctx_block_ptr(p, b, kv, blk);
             if (p.kv_type == 0)
@@ -1064,9 +1073,13 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     }
     const bool bf = q.act_type == MI355Q_BF16;
     const dim3 pgrid(q.max_context_length, q.batch);
-    const size_t plds = (hidden + q.head_size) * sizeof(float);
+    a.raw_k_cache = q.position_shift_enabled ? 1 : 0;
+    if (a.raw_k_cache)
+        MQ_CHECK(q.position_embedding_type == 1 || q.position_embedding_type == 2,
+            "position_shift_enabled needs a rotary position embedding (type %d)", q.position_embedding_type);
+    const size_t plds = (hidden + q.head_size + (a.raw_k_cache ? (size_t) q.num_kv_heads * q.head_size : 0)) * sizeof(float);
     MQ_CHECK(plds <= 64 * 1024, "qkv hidden size %zu too large for the prepare kernel", hidden);
-    const bool fast = dh_pad == q.head_size && q.head_size <= 128 // (the fast kernel's cos / sin table holds 64 pairs)
+    const bool fast = !a.raw_k_cache && dh_pad == q.head_size && q.head_size <= 128 // (the fast kernel's cos / sin table holds 64 pairs)
         && (q.position_embedding_type == 0 || q.position_embedding_type == 1 || q.position_embedding_type == 3
             || q.position_embedding_type == 4 || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size));
     if (fast && bf)

@@ -137,7 +137,14 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     // reference reads kv_loop_length slots and overwrites afterwards, :2207, :2469): then the split that reads the
     // slot writes it, after its own loop and a barrier; otherwise nobody reads the slot and the last split writes early.
     const int slot = kv_slot(p, tl);
-    const bool wrapped = slot < kv_len;
+    // POS_SHIFT (general form): the live tokens are read at kv_pos_slot(position); the slot about to be overwritten is
+    // live iff the token cyc_len before this one is still inside the window, and it is then read at position `sink`
+    const bool pos_shift = GEN && p.shift_k != nullptr;
+    const int old_token = tl - p.cyc_len;
+    const bool wrapped = pos_shift
+        ? (old_token >= p.sink && old_token >= (tl > p.kv_window ? p.sink + tl - p.kv_window : p.sink))
+        : slot < kv_len;
+    const int wrapped_pos = pos_shift ? p.sink : slot; // the loop index at which that slot is read
     auto append_new_token = [&]()
     {
         if (wave == 0 && ts == 0 && appends && ch_live)
@@ -168,7 +175,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
                     vv[e] = KVT == 1 ? float_to_int8_sat(v_s[ch * E + e] * qs) : float_to_fp8(v_s[ch * E + e] * qs);
                 }
             }
-            *reinterpret_cast<uint4*>(kv_block_ptr(p, b, 0, blk) + row) = kw;
+            if (!pos_shift) // POS_SHIFT: the shift kernel has stored the un-rotated key
+                *reinterpret_cast<uint4*>(kv_block_ptr(p, b, 0, blk) + row) = kw;
             *reinterpret_cast<uint4*>(kv_block_ptr(p, b, 1, blk) + row) = vw;
         }
     };
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
         const int ntiles = (kv_len + TILE - 1) / TILE;
         const int tps = (ntiles + p.splits - 1) / p.splits;
         const int tile_end = min(ntiles, (split + 1) * tps);
-        writes_after_loop = wrapped && (slot / TILE) / tps == split;
+        writes_after_loop = wrapped && (wrapped_pos / TILE) / tps == split;
         const size_t head_off = (size_t) hk * p.head_tokens * hs * KVB + (size_t) ch * 16;
         // beams: tokens before beam0_context_length come from beam 0 of the batch entry, later ones from the beam
         // cache_indir names; with a wrapped cyclic cache the context may be overwritten: 0 (Template.h:1497-1498)
@@ -204,9 +212,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
                 if (valid[0] && ch_live)
                 {
                     const int seq = beam_w > 1 ? seq0 + (t < beam0_ctx ? 0 : indir[t]) : b;
-                    const int blk = t >> p.tpb_log2;
-                    const size_t off = head_off + (size_t) (t & (tpb - 1)) * hs * KVB;
-                    kreg[0] = *reinterpret_cast<const uint4*>(kv_block_ptr(p, seq, 0, blk) + off);
+                    const int sl = pos_shift ? kv_pos_slot(p, t, tl) : t;
+                    const int blk = sl >> p.tpb_log2;
+                    const size_t off = head_off + (size_t) (sl & (tpb - 1)) * hs * KVB;
+                    const char* kblock = pos_shift ? p.shift_k + ((size_t) seq * p.max_blocks + blk) * p.shift_block_bytes
+                                                   : kv_block_ptr(p, seq, 0, blk);
+                    kreg[0] = *reinterpret_cast<const uint4*>(kblock + off);
                     vreg[0] = *reinterpret_cast<const uint4*>(kv_block_ptr(p, seq, 1, blk) + off);
                 }
             }
@@ -382,6 +393,105 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
     }
     __syncthreads();
     finish_states<T, G, DH, NW * 64, NW, PAD>(p, b * heads_in_grid + hg, (size_t) b * Hq + hq0, split, red);
+}
+
+// ---- POS_SHIFT (StreamingLLM): the step's rotated copy of the live keys.  The reference runs invokeShiftKCache
+// (unfusedAttentionKernels.cu:1776-1947; gptAttentionCommon.cpp:1276-1290) in front of every generation step: the K cache
+// holds keys without position embedding, the kernel rotates the key at window position x (the sink tokens, then the
+// last window - sink tokens in age order) to position x and writes it, in T, to a scratch cache the attention kernel
+// reads instead.  Same here, with the scratch in the cache's own block structure (`shift_k`) so that the attention
+// kernel keeps its addressing; and this kernel also stores the NEW token's un-rotated key (bias added, rounded to T)
+// into the real cache (k_wo_pos, Template.h:1745-1752, 2216-2233) -- in the workgroup that has just read the slot when
+// the slot still holds a live token, else in the extra workgroup x == kv_len.
+// grid (positions + 1, batch), block 256.  16-bit caches.
+template <typename T>
+__global__ __launch_bounds__(256) void shift_k_cache_kernel(DecodeArgs p)
+{
+    const int x = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tl = p.seq_lens[b] - 1;
+    const int kv_len = min(tl, p.kv_window);
+    if (x > kv_len)
+        return;
+    const int Hq = p.num_heads, Hkv = p.num_kv_heads, D = p.hs;
+    const int tpb = 1 << p.tpb_log2;
+    const int cyc_start = tl > p.kv_window ? p.sink + tl - p.kv_window : p.sink;
+    const int old_token = tl - p.cyc_len;
+    const bool old_live = old_token >= p.sink && old_token >= cyc_start;
+    const int slot_new = kv_slot(p, tl);
+    auto store_new_key = [&]()
+    {
+        const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (size_t) b * (Hq + 2 * Hkv) * D + (size_t) Hq * D;
+        const uint16_t* bias = p.qkv_bias ? reinterpret_cast<const uint16_t*>(p.qkv_bias) + (size_t) Hq * D : nullptr;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(kv_block_ptr(p, b, 0, slot_new >> p.tpb_log2));
+        for (int e = tid; e < Hkv * D; e += 256)
+        {
+            const int hk = e / D, d = e % D;
+            uint16_t w = qkv[e];
+            if (bias)
+                w = T16<T>::from_float(T16<T>::to_float(w) + T16<T>::to_float(bias[e])); // the add is done in T
+            dst[((size_t) hk * p.head_tokens + (slot_new & (tpb - 1))) * D + d] = w;
+        }
+    };
+    if (x == kv_len)
+    {
+        if (!old_live)
+            store_new_key();
+        return;
+    }
+    __shared__ float tab[256]; // cos | sin of pair j at [2j], [2j + 1]; rot_dim / 2 <= 128
+    const int half = p.rot_dim >> 1;
+    if (tid < half)
+    {
+        // update_rotary_base_n_scale at the cache length (unfusedAttentionKernels.cu:1826-1827), angle of position x
+        float base = p.rot_base, scale = p.rot_scale;
+        if (p.rot_scale_type == 2)
+        {
+            if (kv_len > p.rot_max_pos)
+            {
+                const float bb = kv_len * (scale / p.rot_max_pos) - (scale - 1.f);
+                base = base * powf(bb, (float) p.rot_dim / (float) (p.rot_dim - 2));
+            }
+            scale = 1.f;
+        }
+        else if (p.rot_scale_type == 1)
+            scale = 1.f / scale;
+        const float ang = ((float) x * scale) / powf(base, (float) (2 * tid) / (float) p.rot_dim);
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        tab[2 * tid] = cs;
+        tab[2 * tid + 1] = sn;
+    }
+    __syncthreads();
+    const int tok = x < p.sink ? x : cyc_start + (x - p.sink);
+    const int sl = kv_slot(p, tok);
+    const int blk = sl >> p.tpb_log2, tin = sl & (tpb - 1);
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(kv_block_ptr(p, b, 0, blk));
+    uint16_t* dst = reinterpret_cast<uint16_t*>(const_cast<char*>(p.shift_k) + ((size_t) b * p.max_blocks + blk) * p.shift_block_bytes);
+    for (int i = tid; i < Hkv * (D / 2); i += 256)
+    {
+        const int hk = i / (D / 2), j = i % (D / 2);
+        const size_t row = ((size_t) hk * p.head_tokens + tin) * D;
+        if (j < half)
+        {
+            const int i0 = p.pos_type == 2 ? j : 2 * j;
+            const int i1 = p.pos_type == 2 ? j + half : 2 * j + 1;
+            const float cs = tab[2 * j], sn = tab[2 * j + 1];
+            const float a = T16<T>::to_float(src[row + i0]), c = T16<T>::to_float(src[row + i1]);
+            dst[row + i0] = T16<T>::from_float(cs * a - sn * c);
+            dst[row + i1] = T16<T>::from_float(cs * c + sn * a);
+        }
+        else // elements past rotary_embedding_dim pass through
+        {
+            const int e0 = p.rot_dim + 2 * (j - half);
+            dst[row + e0] = src[row + e0];
+            dst[row + e0 + 1] = src[row + e0 + 1];
+        }
+    }
+    if (old_live && tok == old_token) // this workgroup has read the slot the new key goes to
+    {
+        __syncthreads();
+        store_new_key();
+    }
 }
 
 int ilog2(int x)
@@ -591,10 +701,22 @@ Plan make_plan(const mi355q_decode_attention_params& q)
     const int g = q.num_heads / q.num_kv_heads;
     const int tpw = 64 / (dhp / (16 / pl.kvb));
     const int tpb = linear ? (1 << 30) : q.tokens_per_block;
-    pl.gqa = beams == 1 && !q.alibi_slopes && gqa_mfma_applies(q); // ALiBi: the dot-product kernels add the bias
-    // the general form: beams, head sizes / head ratios the grouped kernels are not built for, tiny blocks
+    const bool pos_shift = q.position_shift_enabled != 0;
+    if (pos_shift)
+    {
+        MQ_CHECK(q.position_embedding_type == 1 || q.position_embedding_type == 2,
+            "position_shift_enabled needs a rotary position embedding (type %d)", q.position_embedding_type);
+        if (q.kv_type != q.act_type)
+            MQ_UNSUPPORTED("position_shift_enabled with an 8-bit kv cache is not built (the rotated keys of a step are kept in T)");
+        if (beams > 1)
+            MQ_UNSUPPORTED("position_shift_enabled with beam search is not built");
+    }
+    pl.gqa = beams == 1 && !q.alibi_slopes && !pos_shift && gqa_mfma_applies(q); // ALiBi: the dot-product kernels add the bias
+    // the general form: beams, head sizes / head ratios the grouped kernels are not built for, tiny blocks, and the
+    // position shift (a token's slot is then a function of its position: per-lane addressing)
     pl.general = !pl.gqa
-        && (beams > 1 || !(g == 1 || g == 2 || g == 4 || g == 8) || !(q.head_size == 64 || q.head_size == 128) || tpb < tpw);
+        && (beams > 1 || pos_shift || !(g == 1 || g == 2 || g == 4 || g == 8) || !(q.head_size == 64 || q.head_size == 128)
+            || tpb < tpw);
     pl.groups = q.batch * (pl.general ? q.num_heads : q.num_kv_heads);
     if (pl.gqa)
     {
@@ -631,6 +753,16 @@ size_t partials_bytes(const mi355q_decode_attention_params& q, const Plan& pl)
 {
     return (size_t) pl.groups * group_floats(q, pl) * sizeof(float);
 }
+// POS_SHIFT: one 16-bit K block per cache block of every sequence (a linear cache: one "block" per sequence)
+size_t shift_block_bytes(const mi355q_decode_attention_params& q)
+{
+    const size_t tokens = q.kv_linear_buffer ? (size_t) q.linear_max_seq_len : (size_t) q.tokens_per_block;
+    return (size_t) q.num_kv_heads * tokens * q.head_size * 2;
+}
+size_t shift_k_bytes(const mi355q_decode_attention_params& q)
+{
+    return (size_t) q.batch * (q.kv_linear_buffer ? 1 : q.max_blocks_per_seq) * shift_block_bytes(q);
+}
 } // namespace
 
 size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
@@ -642,7 +774,10 @@ size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
                                                : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
     const size_t groups = (size_t) q.batch * q.num_heads; // the general form has one group per query head
     // records + the per-group padding to a line
-    return rows * q.num_heads * (padded_head_size(q.head_size) + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);
+    size_t bytes = rows * q.num_heads * (padded_head_size(q.head_size) + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);
+    if (q.position_shift_enabled)
+        bytes = (bytes + 255) / 256 * 256 + shift_k_bytes(q); // the step's rotated keys (shift_k_cache, gptAttentionCommon.cpp:1260-1262)
+    return bytes;
 }
 
 #ifdef MI355Q_LAB
@@ -721,14 +856,29 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
     else
         MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in decode (0 - 4)",
             q.position_embedding_type);
+    const size_t need_partials = pl.splits > 1 ? partials_bytes(q, pl) : 0;
     if (pl.splits > 1)
     {
-        const size_t need = partials_bytes(q, pl);
-        MQ_CHECK(q.workspace && q.workspace_bytes >= need, "workspace too small: %zu < %zu", q.workspace_bytes, need);
+        MQ_CHECK(q.workspace && q.workspace_bytes >= need_partials, "workspace too small: %zu < %zu", q.workspace_bytes, need_partials);
         MQ_CHECK(((uintptr_t) q.workspace & 127) == 0, "workspace must be 128-byte aligned");
         a.group_floats = (int) group_floats(q, pl);
         a.partials = reinterpret_cast<float*>(q.workspace);
         a.arrivals = arrival_lines((size_t) pl.groups, stream);
+    }
+    if (q.position_shift_enabled)
+    {
+        // the step's rotated keys behind the partials; the shift kernel fills them (and stores the new un-rotated key)
+        const size_t off = (need_partials + 255) / 256 * 256, need = off + shift_k_bytes(q);
+        MQ_CHECK(q.workspace && q.workspace_bytes >= need,
+            "position_shift_enabled: workspace too small: %zu < %zu (mi355q_decode_attention_workspace_size)", q.workspace_bytes, need);
+        MQ_CHECK(((uintptr_t) q.workspace & 15) == 0, "workspace must be 16-byte aligned");
+        a.shift_k = static_cast<const char*>(q.workspace) + off;
+        a.shift_block_bytes = shift_block_bytes(q);
+        const dim3 grid(std::min(q.max_seq_len - 1, pl.window) + 1, q.batch);
+        if (q.act_type == MI355Q_BF16)
+            hipLaunchKernelGGL(shift_k_cache_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL(shift_k_cache_kernel<f16_t>, grid, dim3(256), 0, stream, a);
     }
 #ifdef MI355Q_LAB
     a.stamps = lab_decode_stamps();
@@ -796,6 +946,7 @@ size_t decode_attention_static_scratch_bytes()
 void masked_multihead_attention_static(const mi355q_decode_attention_params& q, hipStream_t stream)
 {
     const Plan pl = make_plan(q);
+    MQ_CHECK(!q.position_shift_enabled, "position_shift_enabled needs the workspace entry point (the step's rotated keys)");
     mi355q_decode_attention_params c = q;
     c.workspace = nullptr;
     c.workspace_bytes = 0;

@@ -46,6 +46,12 @@ struct DecodeArgs
     int pos_type, rot_dim, rot_scale_type, rot_max_pos;
     float rot_base, rot_scale;
     float score_scale; // 1 / (sqrt(Dh) * q_scaling)
+    // POS_SHIFT (general kernel only): keys are read from `shift_k`, this step's rotated copy of the K cache in the
+    // cache's own block structure ([sequence][block] blocks of shift_block_bytes), at the slot of the token that holds
+    // window position t; q / the new k are rotated to position kv_len; the new k is NOT appended here (the shift
+    // kernel stores it un-rotated)
+    const char* shift_k;
+    size_t shift_block_bytes;
 #ifdef MI355Q_LAB
     unsigned long long* stamps; // lab: [workgroup][16] s_memrealtime stamps (100 MHz), or null
 #endif
@@ -101,6 +107,17 @@ inline CyclicLayout cyclic_layout(bool linear, int capacity, int max_blocks, int
 __device__ __forceinline__ int kv_slot(const DecodeArgs& p, int t)
 {
     return t < p.sink ? t : p.sink + p.bubble + (t - p.sink) % p.cyc_len;
+}
+
+// POS_SHIFT: the cache slot of the token at window position x when `tl` tokens are cached: the sink tokens keep their
+// places, position x >= sink is sequence token cyc_start + (x - sink) with cyc_start the oldest live non-sink token
+// (shiftKCache's token_idx, unfusedAttentionKernels.cu:1790-1795; Template.h:1918-1927 reads the same slots)
+__device__ __forceinline__ int kv_pos_slot(const DecodeArgs& p, int x, int tl)
+{
+    if (x < p.sink)
+        return x;
+    const int cyc_start = tl > p.kv_window ? p.sink + tl - p.kv_window : p.sink;
+    return kv_slot(p, cyc_start + (x - p.sink));
 }
 
 // base of the K (kv = 0) or V (kv = 1) block `blk` of sequence `seq` (getKBlockPtr / getVBlockPtr, :101-137, :302-331)
@@ -233,6 +250,8 @@ __device__ __forceinline__ void stage_new_token(
     const DecodeArgs& p, const NewTokenRegs<G, DH>& r, int tl, float* smem, float early_pow)
 {
     const int tid = threadIdx.x;
+    if (p.shift_k) // POS_SHIFT: the position of the current step is the kv loop length (Template.h:1500)
+        tl = min(tl, p.kv_window);
     {
         // cos / sin of the token's angles depend on the pair index only: one table per block (rot_dim / 2 entries)
         // instead of powf + sincosf for every (head, pair) -- with 8 query heads per kv head that was 9x the

@@ -1289,6 +1289,7 @@ struct GPTAttentionPlugin : PluginBase
         p.rotary_embedding_max_positions = f.rotary_embedding_max_positions;
         p.q_scaling = f.q_scaling;
         p.multi_block_mode = 0;
+        p.position_shift_enabled = f.pos_shift_enabled ? 1 : 0; // mPosShiftEnabled, gptAttentionCommon.cpp:1276-1290, :1345
         return p;
     }
     mi355q_context_attention_params contextParams(int batch, int max_blocks, int max_len, int tokens) const
@@ -1312,6 +1313,7 @@ struct GPTAttentionPlugin : PluginBase
         p.rotary_embedding_scale = f.rotary_embedding_scale;
         p.rotary_embedding_max_positions = f.rotary_embedding_max_positions;
         p.q_scaling = f.q_scaling;
+        p.position_shift_enabled = f.pos_shift_enabled ? 1 : 0; // mPosShiftEnabled, gptAttentionCommon.cpp:834, :1276-1290, :1345
         return p;
     }
     size_t workspaceSize(const mi355q_tensor_desc* in, int, const mi355q_tensor_desc*, int) const override
@@ -1363,8 +1365,8 @@ struct GPTAttentionPlugin : PluginBase
             MQ_CHECK(f.remove_input_padding && f.paged_kv_cache, "mixed requests require remove_input_padding and paged_kv_cache");
         if (nbSeq == 0)
             return;
-        if (f.cross_attention || f.is_medusa_enabled || f.unfuse_qkv_gemm || f.pos_shift_enabled)
-            MQ_UNSUPPORTED("GPTAttention: cross attention / medusa / unfused qkv / pos_shift are not built");
+        if (f.cross_attention || f.is_medusa_enabled || f.unfuse_qkv_gemm)
+            MQ_UNSUPPORTED("GPTAttention: cross attention / medusa / unfused qkv are not built");
         if (f.use_cache && !f.paged_kv_cache)
         {
             // the contiguous cache is output 1, aliased to the past_key_value input by the engine; copy when it is not

@@ -105,6 +105,7 @@ class DecodeAttentionParams(C.Structure):
         ("cache_indirection", C.c_void_p), ("input_lengths", C.c_void_p),
         ("kv_linear_buffer", C.c_void_p), ("linear_max_seq_len", C.c_int32),
         ("alibi_slopes", C.c_void_p),
+        ("position_shift_enabled", C.c_int32),
     ]
 
 
@@ -126,6 +127,7 @@ class ContextAttentionParams(C.Structure):
         ("sequence_lengths", C.c_void_p), ("max_kv_length", C.c_int32),
         ("cyclic_attention_window_size", C.c_int32), ("sink_token_length", C.c_int32),
         ("alibi_slopes", C.c_void_p),
+        ("position_shift_enabled", C.c_int32),
     ]
 
 

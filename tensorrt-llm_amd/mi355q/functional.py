@@ -367,7 +367,7 @@ def make_gpt_attention_plugin(*, num_heads, num_kv_heads, head_size, dtype, laye
                               rotary_embedding_max_positions=1024, kv_cache_quant_mode=0,
                               remove_input_padding=False, paged_kv_cache=True, tokens_per_block=64,
                               max_context_length=0, qkv_bias_enabled=False, multi_block_mode=False,
-                              enable_xqa=True, tp_size=1, tp_rank=0, use_paged_context_fmha=False):
+                              enable_xqa=True, tp_size=1, tp_rank=0, use_paged_context_fmha=False, pos_shift_enabled=False):
     """Field collection of tensorrt_llm/functional.py:3871-3925 / gptAttentionCommon.cpp:1561-1593."""
     I8, I32, F32 = L.FIELD_INT8, L.FIELD_INT32, L.FIELD_FLOAT32
     fields = [
@@ -385,7 +385,7 @@ def make_gpt_attention_plugin(*, num_heads, num_kv_heads, head_size, dtype, laye
         ("paged_kv_cache", int(paged_kv_cache), I32), ("tokens_per_block", tokens_per_block, I32),
         ("type_id", str_dtype_to_trt(dtype), I32), ("max_context_length", max_context_length, I32),
         ("qkv_bias_enabled", int(qkv_bias_enabled), I8), ("do_cross_attention", 0, I8), ("max_distance", 0, I32),
-        ("pos_shift_enabled", 0, I8), ("dense_context_fmha", 0, I8),
+        ("pos_shift_enabled", 1 if pos_shift_enabled else 0, I8), ("dense_context_fmha", 0, I8),
         ("use_paged_context_fmha", int(use_paged_context_fmha), I8),
         ("use_cache", 1, I32), ("is_medusa_enabled", 0, I8),
     ]

@@ -35,7 +35,7 @@ def _fill(slots, seq_lens, cmap, dtype, kv_dtype, kv_scale, gen):
 
 
 def _run(dev, B, Hq, Hkv, D, seq_lens, dtype, kv_dtype=None, tpb=64, max_blocks=None, window=0, sink=0, linear=False,
-         beam_width=1, rope="neox", seed=3, multi_block=0, via_plugin=False):
+         beam_width=1, rope="neox", seed=3, multi_block=0, via_plugin=False, pos_shift=False):
     kv_dtype = kv_dtype or dtype
     gen = torch.Generator().manual_seed(seed)
     capacity = (max_blocks * tpb) if not linear else max_blocks * tpb
@@ -73,7 +73,7 @@ def _run(dev, B, Hq, Hkv, D, seq_lens, dtype, kv_dtype=None, tpb=64, max_blocks=
         plg = F.make_gpt_attention_plugin(
             num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="float16" if dtype == torch.float16 else "bfloat16",
             position_embedding_type={None: 0, "gptj": 1, "neox": 2}[rope], rotary_embedding_dim=D if rope else 0,
-            kv_cache_quant_mode=qm, paged_kv_cache=not linear, tokens_per_block=tpb)
+            kv_cache_quant_mode=qm, paged_kv_cache=not linear, tokens_per_block=tpb, pos_shift_enabled=pos_shift)
         lens = torch.tensor(seq_lens, dtype=torch.int32)
         ins = [d_qkv.reshape(B, 1, -1), d_lens, lens - 1, torch.tensor([win], dtype=torch.int32),
                torch.tensor([sink], dtype=torch.int32),
@@ -104,6 +104,7 @@ def _run(dev, B, Hq, Hkv, D, seq_lens, dtype, kv_dtype=None, tpb=64, max_blocks=
         p.rotary_embedding_scale_type, p.rotary_embedding_scale, p.rotary_embedding_max_positions = 0, 1.0, 4096
         p.q_scaling, p.multi_block_mode = 1.0, multi_block
         p.cyclic_attention_window_size, p.sink_token_length = window, sink
+        p.position_shift_enabled = 1 if pos_shift else 0
         keep = []
         if kv_dtype != dtype:
             so = torch.tensor([1.0 / kv_scale], dtype=torch.float32, device=dev)
@@ -126,7 +127,8 @@ def _run(dev, B, Hq, Hkv, D, seq_lens, dtype, kv_dtype=None, tpb=64, max_blocks=
     ref_slots = slots.clone()
     ref = oracle.decode_attention_slots(qkv, ref_slots, seq_lens, Hq, Hkv, D, cmap, rope=rope, rot_dim=D if rope else 0,
                                         kv_scale_orig_quant=1.0 / kv_scale, kv_scale_quant_orig=kv_scale,
-                                        beam_width=beam_width, cache_indir=indir, input_lengths=input_lengths)
+                                        beam_width=beam_width, cache_indir=indir, input_lengths=input_lengths,
+                                        pos_shift=pos_shift)
     err = (out.cpu().float() - ref.float()).abs().max().item()
     assert err <= ATOL[dtype], f"output differs from the oracle by {err}"
     # the cache after the step: exactly the oracle's (the new token in its slot, nothing else touched)
@@ -139,7 +141,7 @@ def _run(dev, B, Hq, Hkv, D, seq_lens, dtype, kv_dtype=None, tpb=64, max_blocks=
     # appended line, the allowance of test_gpu_attention.py
     def codes(x):
         return x.view(torch.uint8) if kv_dtype == torch.float8_e4m3fn else x
-    exact = slice(None) if rope is None else slice(1, 2)
+    exact = slice(None) if (rope is None or pos_shift) else slice(1, 2)   # POS_SHIFT stores the key un-rotated: exact too
     a, b = codes(got[:, exact]), codes(ref_slots[:, exact])
     if not torch.equal(a, b):
         bad = (a != b).any(-1).nonzero()[:8].tolist()
@@ -285,3 +287,86 @@ def test_linear_cache_context_then_generation_through_the_plugin(cuda, kv_dtype)
     err = (out.float() - ref.float()).abs().max().item()
     assert err <= 2e-3, f"generation output differs by {err}"
     assert torch.equal(dcache.cpu()[:, 1], ref_cache.data[:, 1]), "V line of the new token differs"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rope", ["neox", "gptj"])
+def test_position_shift_streamingllm(cuda, dtype, rope):
+    """position_shift_enabled (StreamingLLM): the cache holds un-rotated keys, the step rotates the live keys to their
+    position inside the cache, q / the new key to position min(kv length, window), and stores the new key un-rotated
+    (oracle.decode_attention_slots pos_shift: invokeShiftKCache + the POS_SHIFT branches of the masked-MHA kernel).  The
+    reference's own StreamingLLM cases (tests/attention/test_gpt_attention.py:188-192: llama, sink 4, pos shift on / off)
+    run with the window at the sequence length; here also past the wrap, with sink tokens (bubble: 4 % 64 != 0), in
+    one-more-block mode, on a linear cache, GQA, forced kv splits and through the plugin.  Parity unpinned beyond that grid."""
+    # window >= every length, no sink: positions are the token indices (the reference's own cases)
+    _run(cuda, 3, 4, 4, 64, [40, 129, 100], dtype, tpb=64, max_blocks=3, rope=rope, pos_shift=True)
+    # window 128 over 2 blocks (no spare block): lengths below, at and past the wrap, sink 4 with a bubble
+    _run(cuda, 4, 4, 4, 128, [40, 129, 130, 300], dtype, tpb=64, max_blocks=3, window=100, sink=4, rope=rope, pos_shift=True, seed=11)
+    # one-more-block mode (window 128 in 3 blocks), GQA 8:2, forced splits
+    _run(cuda, 3, 8, 2, 128, [129, 200, 450], dtype, tpb=64, max_blocks=3, window=128, rope=rope, pos_shift=True, multi_block=3, seed=12)
+    # contiguous cache, window with sink tokens
+    _run(cuda, 2, 4, 2, 64, [150, 60], dtype, tpb=1, max_blocks=96, window=80, sink=3, linear=True, rope=rope, pos_shift=True, seed=13)
+    # and through the plugin's input list
+    _run(cuda, 2, 4, 4, 128, [260, 77], dtype, tpb=64, max_blocks=4, window=192, sink=4, rope=rope, pos_shift=True, via_plugin=True, seed=14)
+
+
+def test_position_shift_refusals(cuda):
+    p = L.DecodeAttentionParams()
+    p.batch, p.num_heads, p.num_kv_heads, p.head_size = 1, 4, 4, 64
+    p.max_blocks_per_seq, p.tokens_per_block, p.max_seq_len = 2, 64, 100
+    p.act_type, p.kv_type = L.HALF, L.INT8
+    p.position_embedding_type, p.rotary_embedding_dim, p.position_shift_enabled = 2, 64, 1
+    assert L.lib().mi355q_masked_multihead_attention(C.byref(p), None) == -2          # 8-bit cache: MI355Q_ERR_UNSUPPORTED
+    p.kv_type, p.position_embedding_type = L.HALF, 0
+    assert L.lib().mi355q_masked_multihead_attention(C.byref(p), None) == -1          # no rotary embedding to shift
+
+
+def test_position_shift_context_then_generation_through_the_plugin(cuda):
+    """pos_shift_enabled through the plugin: the context phase stores K without the rotation (bit-exact against the
+    oracle: no sin / cos is involved), its outputs are those of the plain context phase; a generation step then continues
+    on that cache.  With the window at the sequence length and no sink tokens every key gets the position it has in the
+    sequence, so the step also has to agree with the un-shifted pipeline (the reference's StreamingLLM grid compares
+    exactly these two, tests/attention/test_gpt_attention.py:188-192)."""
+    dtype, Hq, Hkv, D, S = torch.float16, 8, 2, 128, 150
+    lens = [37, 64, 5]
+    B = len(lens)
+    g = torch.Generator().manual_seed(7)
+    rows = [(torch.randn(n, (Hq + 2 * Hkv) * D, generator=g) * 0.5).to(dtype) for n in lens]
+    qkv = (torch.randn(B, (Hq + 2 * Hkv) * D, generator=g) * 0.5).to(dtype)
+    L32 = torch.tensor(lens, dtype=torch.int32)
+    outs_gen = {}
+    for shift in (True, False):
+        plg = F.make_gpt_attention_plugin(num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="float16",
+                                          position_embedding_type=2, rotary_embedding_dim=D, remove_input_padding=True,
+                                          paged_kv_cache=False, tokens_per_block=64, pos_shift_enabled=shift)
+        dcache = torch.zeros(B, 2, Hkv, S, D, dtype=dtype, device=cuda)
+
+        def enqueue(x, seq, past, ctx, req):
+            out = torch.zeros(x.shape[0], Hq * D, dtype=dtype, device=cuda)
+            ins = [x.to(cuda), seq.to(cuda), past, torch.tensor([S], dtype=torch.int32), torch.zeros(1, dtype=torch.int32),
+                   ctx.to(cuda), torch.zeros(B, 1, S, dtype=torch.int32, device=cuda), req, dcache, ctx]
+            plg.configure(ins)
+            ws = torch.empty(max(plg.get_workspace_size(ins, [out, dcache]), 1), dtype=torch.uint8, device=cuda)
+            plg.enqueue(ins, [out, dcache], ws)
+            torch.cuda.synchronize()
+            return out.cpu()
+
+        ref_cache = _LinearCache(B, Hkv, S, D, dtype)
+        out = enqueue(torch.cat(rows, 0), L32, torch.zeros(B, dtype=torch.int32), L32, torch.zeros(B, dtype=torch.int32))
+        ref = oracle.context_attention(rows, lens, Hq, Hkv, D, cache=ref_cache, rope="neox", rot_dim=D, pos_shift=shift)
+        err = max((out[sum(lens[:b]):sum(lens[:b + 1])].float() - ref[b].float()).abs().max().item() for b in range(B))
+        assert err <= 5e-3, f"context output differs by {err} (pos_shift {shift})"
+        got = dcache.cpu()
+        if shift:
+            assert torch.equal(got, ref_cache.data), "the context phase must store K un-rotated, bit for bit"
+            slots = got.clone()
+            cmap = oracle.CyclicMap(S, 0, linear=True)
+            seq = (L32 + 1).tolist()
+            ref_gen = oracle.decode_attention_slots(qkv, slots, seq, Hq, Hkv, D, cmap, rope="neox", rot_dim=D, pos_shift=True)
+        outs_gen[shift] = enqueue(qkv, L32 + 1, L32, L32, torch.ones(B, dtype=torch.int32))
+        if shift:
+            err = (outs_gen[True].float() - ref_gen.float()).abs().max().item()
+            assert err <= 2e-3, f"generation output with pos_shift differs from the oracle by {err}"
+            assert torch.equal(dcache.cpu(), slots), "the generation step must append the un-rotated key / the value"
+    err = (outs_gen[True].float() - outs_gen[False].float()).abs().max().item()
+    assert err <= 4e-3, f"pos_shift and plain pipelines disagree by {err} where every position equals the token index"
