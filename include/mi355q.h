@@ -402,6 +402,15 @@ extern "C"
          * mi355q_decode_attention_workspace_size reports (the rotated keys of the step: the reference's
          * shift_k_cache, :1260-1262). */
         int32_t position_shift_enabled;
+        /* relative attention bias (position_embedding_type 5, kRELATIVE; Multihead_attention_params::
+         * relative_attention_bias / relative_attention_bias_stride / max_distance, Template.h:1469-1476, 1773-1797,
+         * 1960-1985, 2026): act_type values added to the scaled scores.  max_distance == 0: the explicit tensor
+         * [num_heads, stride, stride], entry [h][kv length][t]; max_distance > 0: the table [num_heads, stride = num_buckets]
+         * and the bucket of (t - kv length) computed on the fly.  NULL otherwise.  Generation only (the context phase
+         * with a relative bias is not built). */
+        const void* relative_attention_bias;
+        int32_t relative_attention_bias_stride;
+        int32_t max_distance;
     } mi355q_decode_attention_params;
     size_t mi355q_decode_attention_workspace_size(const mi355q_decode_attention_params* params);
     mi355q_status mi355q_masked_multihead_attention(const mi355q_decode_attention_params* params, void* stream);

@@ -487,9 +487,26 @@ def quantize_kv(x, kv_dtype, scale_orig_quant):
     return x.to(kv_dtype)
 
 
+def relative_bucket_mmha(relative_position, num_buckets, max_distance):
+    """The bucket of a relative position as the masked-MHA kernel computes it on the fly
+    (decoderMaskedMultiheadAttentionTemplate.h:1960-1977, IMPLICIT_REL_ATTN_BIAS), fp32 like the kernel."""
+    rb = 0
+    nb = num_buckets // 2
+    if relative_position > 0:
+        rb += nb
+    rp = abs(relative_position)
+    max_exact = nb // 2
+    if rp < max_exact:
+        return rb + rp
+    large = max_exact + int(np.float32(np.log(np.float32(rp) / np.float32(max_exact)))
+                            / np.float32(np.log(np.float32(max_distance) / np.float32(max_exact))) * np.float32(nb - max_exact))
+    return rb + min(large, nb - 1)
+
+
 def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_scaling=1.0, rope=None,
                      rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None, kv_scale_orig_quant=1.0,
-                     kv_scale_quant_orig=1.0, update_cache=True, alibi_slopes=None):
+                     kv_scale_quant_orig=1.0, update_cache=True, alibi_slopes=None, relative_attention_bias=None,
+                     max_distance=0):
     """One generation step of GPTAttention over a paged cache, restating the MMHA math
     (decoderMaskedMultiheadAttentionTemplate.h; conventions pinned by test_gpt_attention.py:1018,1154):
       * seq_lens[b] INCLUDES the current token; tlength = seq_lens[b]-1 cached tokens (:1480-1482)
@@ -497,6 +514,10 @@ def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_
       * bias add, then RoPE at position tlength, results rounded to T (:1602-1711)
       * logits = (q.k) * 1/(sqrt(Dh)*q_scaling) in fp32 (:1797, :2026); ALiBi (alibi_slopes [Hq] in T, :1891-1895):
         + slope[h] * (t - tlength) (:2026)
+      * relative attention bias (position embedding kRELATIVE; T values): logit += bias, after the scaling (:1797,
+        :2026).  max_distance == 0: the explicit tensor [Hq, S, S], bias[h][tlength][t] (:1775-1790, :1982-1985);
+        max_distance > 0: the table [Hq, num_buckets] and the bucket of (t - tlength) computed as the kernel does
+        (:1960-1977: num_buckets halved, max_exact = half of that, logarithmic beyond)
       * p = exp(l - max); out = sum p v / (sum p + 1e-6)  (:2259-2290)
       * the current token uses its un-quantised k/v (registers), cached tokens are dequantised as
         float(k8) * kv_scale_quant_orig (:1999-2003); new k/v are appended at position tlength.
@@ -534,6 +555,13 @@ def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_
                 logits = (kk @ torch.from_numpy(q[h]).double()).float() * np.float32(inv_sqrt)
                 if alibi_slopes is not None:
                     logits = logits + alibi_slopes[h].float() * (torch.arange(tl + 1) - tl).float()
+                if relative_attention_bias is not None:
+                    if max_distance > 0:
+                        idx = torch.tensor([relative_bucket_mmha(t - tl, relative_attention_bias.shape[1], max_distance)
+                                            for t in range(tl + 1)], dtype=torch.long)
+                        logits = logits + relative_attention_bias[h, idx].float()
+                    else:
+                        logits = logits + relative_attention_bias[h, tl, :tl + 1].float()
                 p = torch.exp(logits - logits.max())
                 o = (p.double() @ vv).float() / (p.sum() + 1e-6)
                 out[b, h * D:(h + 1) * D] = o

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
             for (int e = 0; e < EP; ++e)
                 s = dot2<T>(qp[g][e], pack2<T>(kf[2 * e], kf[2 * e + 1]), s);
             s = group_sum<LPT>(s) * (p.score_scale * 1.4426950408889634f);
+            if (p.rel_bias) // the current step's own entry (Template.h:1787-1797)
+                s += T16<T>::to_float(p.rel_bias[rel_bias_index(p, hq0 + g, tl, tl)]) * 1.4426950408889634f;
             m[g] = s;
             l[g] = 1.f;
 #pragma unroll
@@ -282,6 +284,19 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(DecodeArgs p)
 #pragma unroll
                     for (int g = 0; g < G; ++g)
                         s[g][u] = __builtin_fmaf(slope2[g], dist, s[g][u]);
+                }
+            }
+
+            if (p.rel_bias) // wave-uniform.  The loop index stands for the time step, as in the reference's loop
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const int t = t0 + (GEN ? 0 : u * TPW) + ts;
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (valid[u])
+                            s[g][u] += T16<T>::to_float(p.rel_bias[rel_bias_index(p, hq0 + g, t, tl)]) * 1.4426950408889634f;
                 }
             }
 
@@ -711,7 +726,8 @@ Plan make_plan(const mi355q_decode_attention_params& q)
         if (beams > 1)
             MQ_UNSUPPORTED("position_shift_enabled with beam search is not built");
     }
-    pl.gqa = beams == 1 && !q.alibi_slopes && !pos_shift && gqa_mfma_applies(q); // ALiBi: the dot-product kernels add the bias
+    // ALiBi / relative attention bias: the dot-product kernels add the bias
+    pl.gqa = beams == 1 && !q.alibi_slopes && !q.relative_attention_bias && !pos_shift && gqa_mfma_applies(q);
     // the general form: beams, head sizes / head ratios the grouped kernels are not built for, tiny blocks, and the
     // position shift (a token's slot is then a function of its position: per-lane addressing)
     pl.general = !pl.gqa
@@ -853,8 +869,21 @@ void masked_multihead_attention(const mi355q_decode_attention_params& q, hipStre
         MQ_CHECK(q.alibi_slopes, "position_embedding_type %d needs alibi_slopes", q.position_embedding_type);
         a.alibi_slopes = reinterpret_cast<const uint16_t*>(q.alibi_slopes);
     }
+    else if (q.position_embedding_type == 5) // kRELATIVE
+    {
+        MQ_CHECK(q.relative_attention_bias && q.relative_attention_bias_stride > 0,
+            "position_embedding_type 5 needs relative_attention_bias and its stride");
+        if (q.max_distance > 0)
+            MQ_CHECK(q.relative_attention_bias_stride >= 4, "relative attention: %d buckets", q.relative_attention_bias_stride);
+        else
+            MQ_CHECK(q.relative_attention_bias_stride >= q.max_seq_len, "relative_attention_bias [Hq, %d, %d] is smaller than max_seq_len %d",
+                q.relative_attention_bias_stride, q.relative_attention_bias_stride, q.max_seq_len);
+        a.rel_bias = reinterpret_cast<const uint16_t*>(q.relative_attention_bias);
+        a.rel_stride = q.relative_attention_bias_stride;
+        a.max_distance = q.max_distance;
+    }
     else
-        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in decode (0 - 4)",
+        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in decode (0 - 5)",
             q.position_embedding_type);
     const size_t need_partials = pl.splits > 1 ? partials_bytes(q, pl) : 0;
     if (pl.splits > 1)

@@ -52,6 +52,10 @@ struct DecodeArgs
     // kernel stores it un-rotated)
     const char* shift_k;
     size_t shift_block_bytes;
+    // relative attention bias (decode_attn_kernel only): T [Hq][stride][stride] (max_distance == 0) or the bucket table
+    // T [Hq][stride] (Template.h:1773-1797, 1960-1985)
+    const uint16_t* rel_bias;
+    int rel_stride, max_distance;
 #ifdef MI355Q_LAB
     unsigned long long* stamps; // lab: [workgroup][16] s_memrealtime stamps (100 MHz), or null
 #endif
@@ -107,6 +111,23 @@ inline CyclicLayout cyclic_layout(bool linear, int capacity, int max_blocks, int
 __device__ __forceinline__ int kv_slot(const DecodeArgs& p, int t)
 {
     return t < p.sink ? t : p.sink + p.bubble + (t - p.sink) % p.cyc_len;
+}
+
+// index into the relative-attention-bias input for head h, key step t, kv length tl (Template.h:1775-1782 explicit,
+// :1960-1977 implicit: the kernel halves num_buckets, takes max_exact = half of that and a logarithmic bucket beyond)
+__device__ __forceinline__ size_t rel_bias_index(const DecodeArgs& p, int h, int t, int tl)
+{
+    if (p.max_distance <= 0)
+        return ((size_t) h * p.rel_stride + tl) * p.rel_stride + t;
+    const int nb = p.rel_stride / 2;
+    int rp = t - tl, rb = rp > 0 ? nb : 0;
+    rp = abs(rp);
+    const int max_exact = nb / 2;
+    int large = max_exact
+        + (int) (logf(rp * 1.0f / max_exact) / logf((float) p.max_distance / max_exact) * (nb - max_exact));
+    large = min(large, nb - 1);
+    rb += rp < max_exact ? rp : large;
+    return (size_t) h * p.rel_stride + rb;
 }
 
 // POS_SHIFT: the cache slot of the token at window position x when `tl` tokens are cached: the sink tokens keep their

@@ -1467,6 +1467,8 @@ struct GPTAttentionPlugin : PluginBase
         c.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
         if (f.position_embedding_type == 3 || f.position_embedding_type == 4)
             c.alibi_slopes = inputs[getIdx(ALIBI_SLOPES)];
+        if (f.position_embedding_type == 5)
+            MQ_UNSUPPORTED("GPTAttention context phase with a relative attention bias is not built (generation is)");
         c.out = outputs[0];
         c.context_lengths = static_cast<const int32_t*>(inputs[getIdx(CONTEXT_LENGTHS)]) + seqBeg;
         c.workspace = workspace;
@@ -1508,6 +1510,12 @@ struct GPTAttentionPlugin : PluginBase
         p.sequence_lengths = static_cast<const int32_t*>(inputs[getIdx(SEQUENCE_LENGTH)]) + seqBeg;
         if (f.position_embedding_type == 3 || f.position_embedding_type == 4)
             p.alibi_slopes = inputs[getIdx(ALIBI_SLOPES)];
+        if (f.position_embedding_type == 5) // isRelativePosition(), gptAttentionPlugin.cpp:634-640
+        {
+            p.relative_attention_bias = inputs[getIdx(RELATIVE_ATTENTION_BIAS)];
+            p.relative_attention_bias_stride = inDesc[getIdx(RELATIVE_ATTENTION_BIAS)].dims.d[1]; // max_seq_len or num_buckets
+            p.max_distance = f.max_distance;
+        }
         p.block_pointers = bp;
         if (hasKvQuant())
         {

@@ -106,6 +106,7 @@ class DecodeAttentionParams(C.Structure):
         ("kv_linear_buffer", C.c_void_p), ("linear_max_seq_len", C.c_int32),
         ("alibi_slopes", C.c_void_p),
         ("position_shift_enabled", C.c_int32),
+        ("relative_attention_bias", C.c_void_p), ("relative_attention_bias_stride", C.c_int32), ("max_distance", C.c_int32),
     ]
 
 

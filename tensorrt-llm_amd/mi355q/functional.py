@@ -367,7 +367,7 @@ def make_gpt_attention_plugin(*, num_heads, num_kv_heads, head_size, dtype, laye
                               rotary_embedding_max_positions=1024, kv_cache_quant_mode=0,
                               remove_input_padding=False, paged_kv_cache=True, tokens_per_block=64,
                               max_context_length=0, qkv_bias_enabled=False, multi_block_mode=False,
-                              enable_xqa=True, tp_size=1, tp_rank=0, use_paged_context_fmha=False, pos_shift_enabled=False):
+                              enable_xqa=True, tp_size=1, tp_rank=0, use_paged_context_fmha=False, pos_shift_enabled=False, max_distance=0):
     """Field collection of tensorrt_llm/functional.py:3871-3925 / gptAttentionCommon.cpp:1561-1593."""
     I8, I32, F32 = L.FIELD_INT8, L.FIELD_INT32, L.FIELD_FLOAT32
     fields = [
@@ -384,7 +384,7 @@ def make_gpt_attention_plugin(*, num_heads, num_kv_heads, head_size, dtype, laye
         ("remove_input_padding", int(remove_input_padding), I8), ("mask_type", 1, I32),
         ("paged_kv_cache", int(paged_kv_cache), I32), ("tokens_per_block", tokens_per_block, I32),
         ("type_id", str_dtype_to_trt(dtype), I32), ("max_context_length", max_context_length, I32),
-        ("qkv_bias_enabled", int(qkv_bias_enabled), I8), ("do_cross_attention", 0, I8), ("max_distance", 0, I32),
+        ("qkv_bias_enabled", int(qkv_bias_enabled), I8), ("do_cross_attention", 0, I8), ("max_distance", max_distance, I32),
         ("pos_shift_enabled", 1 if pos_shift_enabled else 0, I8), ("dense_context_fmha", 0, I8),
         ("use_paged_context_fmha", int(use_paged_context_fmha), I8),
         ("use_cache", 1, I32), ("is_medusa_enabled", 0, I8),
@@ -395,7 +395,8 @@ def make_gpt_attention_plugin(*, num_heads, num_kv_heads, head_size, dtype, laye
 def gpt_attention(plugin, *, qkv, sequence_length, host_past_key_value_lengths, host_max_attention_window_sizes,
                   host_sink_token_length, context_lengths, cache_indirection, host_request_types,
                   kv_cache_block_pointers, host_kv_cache_block_pointers, kv_orig_quant_scale=None,
-                  kv_quant_orig_scale=None, host_context_lengths=None, qkv_bias=None, alibi_slopes=None):
+                  kv_quant_orig_scale=None, host_context_lengths=None, qkv_bias=None, alibi_slopes=None,
+                  relative_attention_bias=None):
     """tensorrt_llm/functional.py:3487-3930 `gpt_attention` for a paged cache: assembles the plugin
     input list in the order of gptAttentionPlugin.h:43-68 and enqueues.  Returns the context tensor."""
     inputs = [qkv, sequence_length, host_past_key_value_lengths, host_max_attention_window_sizes,
@@ -405,6 +406,8 @@ def gpt_attention(plugin, *, qkv, sequence_length, host_past_key_value_lengths, 
         inputs += [kv_orig_quant_scale, kv_quant_orig_scale]
     if alibi_slopes is not None:
         inputs += [alibi_slopes]
+    if relative_attention_bias is not None:
+        inputs += [relative_attention_bias]
     if host_context_lengths is not None:
         inputs += [host_context_lengths]
     if qkv_bias is not None:

@@ -40,7 +40,8 @@ def build_case(B, Hq, Hkv, D, seq_lens, tpb, dtype, kv_dtype, seed=42, max_seq=N
 
 
 def run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, tpb, dtype, kv_dtype, dev, rope=None, bias=None, kv_scale=1.0,
-               remove_padding=False, num_layers=1, layer_idx=0, alibi=None, pe=None):
+               remove_padding=False, num_layers=1, layer_idx=0, alibi=None, pe=None, rel_bias=None, max_distance=0,
+               q_scaling=1.0):
     B = qkv.shape[0]
     qm = 0
     if kv_dtype == torch.int8:
@@ -52,7 +53,7 @@ def run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, tpb, dtype, kv_dtype, dev, rope
         num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="float16" if dtype == torch.float16 else "bfloat16",
         layer_idx=layer_idx, position_embedding_type=pe, rotary_embedding_dim=D if rope else 0,
         kv_cache_quant_mode=qm, remove_input_padding=remove_padding, paged_kv_cache=True, tokens_per_block=tpb,
-        qkv_bias_enabled=bias is not None)
+        qkv_bias_enabled=bias is not None, max_distance=max_distance, q_scaling=q_scaling)
     pool = cache.pool.to(dev)
     esz = pool.element_size()
     offs = cache.offsets()  # [B, 2, max_blocks] element offsets
@@ -80,6 +81,8 @@ def run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, tpb, dtype, kv_dtype, dev, rope
         kwargs["qkv_bias"] = bias.to(dev)
     if alibi is not None:
         kwargs["alibi_slopes"] = alibi.to(dev)
+    if rel_bias is not None:
+        kwargs["relative_attention_bias"] = rel_bias.to(dev)
     out = F.gpt_attention(plg, **kwargs)
     torch.cuda.synchronize()
     return out.reshape(B, -1).cpu(), pool.cpu()
@@ -148,6 +151,32 @@ def test_decode_alibi(cuda, dtype, Hq, Hkv, D, kv_dtype):
                                        kv_scale_quant_orig=kv_scale, update_cache=False)
         assert (out.float() - ref.float()).abs().max().item() <= ATOL[dtype]
         assert (noal.float() - ref.float()).abs().max().item() > 10 * ATOL[dtype]  # the bias matters in this case
+        assert torch.equal(pool_after.view(torch.uint8), cache.pool.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D,kv_dtype", [(8, 8, 64, None), (8, 2, 128, torch.int8), (12, 4, 32, None)])
+def test_decode_relative_attention_bias(cuda, dtype, Hq, Hkv, D, kv_dtype):
+    # kRELATIVE (5): T5-style bias added to the scaled score (Template.h:1797, :2026), q_scaling = 1 / sqrt(Dh) so that the
+    # score is q.k itself.  Explicit tensor [Hq, S, S] (max_distance 0, entry [h][tlength][t], :1775-1790) and the
+    # implicit bucket table [Hq, num_buckets] with max_distance 128 (:1960-1977).  The reference's attention test has no
+    # relative-bias case for this plugin ("parity unpinned": the oracle restates the cited lines); split-KV lengths.
+    kv_dtype = kv_dtype or dtype
+    seq_lens = [300, 17, 1200]
+    g = torch.Generator().manual_seed(9)
+    for max_distance, shape in ((0, (Hq, 1224, 1224)), (128, (Hq, 32))):
+        rel = (torch.randn(shape, generator=g) * 0.7).to(dtype)
+        cache, qkv, kv_scale = build_case(3, Hq, Hkv, D, seq_lens, 64, dtype, kv_dtype, seed=max_distance + 1)
+        qkv = (qkv.float() * 0.3).to(dtype)     # un-scaled scores: keep them O(1)
+        out, pool_after = run_plugin(cache, qkv, seq_lens, Hq, Hkv, D, 64, dtype, kv_dtype, cuda, kv_scale=kv_scale,
+                                     rel_bias=rel, pe=5, max_distance=max_distance, q_scaling=1.0 / np.sqrt(D))
+        ref = oracle.decode_attention(qkv, cache, seq_lens, Hq, Hkv, D, q_scaling=1.0 / np.sqrt(D),
+                                      kv_scale_orig_quant=1.0 / kv_scale, kv_scale_quant_orig=kv_scale,
+                                      relative_attention_bias=rel, max_distance=max_distance)
+        plain = oracle.decode_attention(qkv, cache, seq_lens, Hq, Hkv, D, q_scaling=1.0 / np.sqrt(D),
+                                        kv_scale_orig_quant=1.0 / kv_scale, kv_scale_quant_orig=kv_scale, update_cache=False)
+        assert (out.float() - ref.float()).abs().max().item() <= ATOL[dtype]
+        assert (plain.float() - ref.float()).abs().max().item() > 10 * ATOL[dtype]  # the bias matters in this case
         assert torch.equal(pool_after.view(torch.uint8), cache.pool.view(torch.uint8))
 
 
