@@ -19,9 +19,9 @@
 //     (hipStreamGetCaptureInfo's id) and the capturing stream, drawn from a pool that is NEVER recycled -- the nodes of
 //     one capture on one stream are a chain, two captures never share, fork / join branches of a capture sit on
 //     different streams and so in different regions.
-// Regions grow by powers of two (a key holds at most twice its largest launch).  Eager regions come from the lower half
-// of the array; when that half is used up (thousands of distinct stream handles) the device is synchronised once and
-// the half is handed out again.  The capture half only fills: when it is exhausted the call fails loudly
+// Regions grow by powers of two (a key holds at most twice its largest launch).  Eager regions come from the first quarter
+// of the array; when that is used up (many distinct stream handles) the device is synchronised once and the quarter is
+// handed out again.  The capture part only fills: when it is exhausted the call fails loudly
 // (a process that captures without end must not).  What stays the caller's duty: the same graph, or two graphs of the
 // same capture, must not run concurrently with themselves (HIP serialises launches of one hipGraphExec_t anyway), and
 // a launch killed half-way (GPU fault) leaves words behind -- as it leaves everything else of that context.
@@ -37,7 +37,7 @@ namespace mi355q
 namespace
 {
 constexpr size_t ARRIVAL_LINES = size_t(1) << 17; // x 128 B = 16 MiB per GPU
-constexpr size_t EAGER_LINES = ARRIVAL_LINES / 2; // [0, EAGER_LINES): streams; [EAGER_LINES, ARRIVAL_LINES): captures
+constexpr size_t EAGER_LINES = ARRIVAL_LINES / 4; // [0, EAGER_LINES): streams; [EAGER_LINES, ARRIVAL_LINES): captures
 constexpr size_t MAX_LAUNCH_LINES = size_t(1) << 15;
 static __device__ __align__(256) uint32_t arrival_ring[ARRIVAL_LINES * 32];
 constexpr int MAX_DEVICES = 64;
@@ -131,7 +131,7 @@ uint32_t* arrival_lines(size_t count, hipStream_t stream)
     {
         if (s.eager_next + lines > EAGER_LINES)
         {
-            // every eager region is idle once the device has drained: start the eager half again
+            // every eager region is idle once the device has drained: start the eager part again
             MQ_HIP(hipDeviceSynchronize());
             for (auto r = s.regions.begin(); r != s.regions.end();)
                 r = std::get<1>(r->first) == 0 ? s.regions.erase(r) : std::next(r);
