@@ -786,8 +786,10 @@ size_t decode_attention_workspace_size(const mi355q_decode_attention_params& q)
     make_plan(q);
     // batch' * splits(batch') <= 1024 / Hkv + batch' for every batch' <= batch, so this bound holds
     // for any smaller batch enqueued later (TensorRT asks once, at configure time, with max shapes)
-    const size_t rows = q.multi_block_mode > 0 ? (size_t) q.batch * q.multi_block_mode
-                                               : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
+    size_t rows = q.multi_block_mode > 0 ? (size_t) q.batch * q.multi_block_mode
+                                         : (size_t) (1024 + q.num_kv_heads - 1) / q.num_kv_heads + q.batch;
+    if (lab_env("MI355Q_ATTN_SPLITS")) // lab: the override of choose_splits_impl
+        rows = std::max(rows, (size_t) q.batch * std::max(1, atoi(lab_env("MI355Q_ATTN_SPLITS"))));
     const size_t groups = (size_t) q.batch * q.num_heads; // the general form has one group per query head
     // records + the per-group padding to a line
     size_t bytes = rows * q.num_heads * (padded_head_size(q.head_size) + PART_PAD) * sizeof(float) + groups * 32 * sizeof(float);

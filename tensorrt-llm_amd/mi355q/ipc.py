@@ -71,10 +71,14 @@ def init_comm(group=None, ranks=None):
     if L.lib().mi355q_comm_exists(arr, world) == 1:
         return
     uid = (C.c_uint8 * L.COMM_UNIQUE_ID_BYTES)()
+    box = [None]
     if rank == 0:
-        L.check(L.lib().mi355q_comm_get_unique_id(uid))
-    box = [bytes(uid)]
+        # a failure here (librccl not loadable) must reach every rank: the others are about to wait for the id
+        rc = L.lib().mi355q_comm_get_unique_id(uid)
+        box = [bytes(uid) if rc == 0 else "error: " + L.lib().mi355q_last_error().decode()]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if isinstance(box[0], str):
+        raise RuntimeError("init_comm: rank 0 could not draw the RCCL unique id (" + box[0] + ")")
     uid = (C.c_uint8 * L.COMM_UNIQUE_ID_BYTES).from_buffer_copy(box[0])
     L.check(L.lib().mi355q_comm_init_rank(arr, world, uid, rank))
 

@@ -261,3 +261,26 @@ def test_fp8_gemm(cuda, out_dtype, m, n, k):
     # products of e4m3 values are exact in fp32; only the fp32 accumulation order differs
     tol = 1e-5 * ref.abs().max().item() * (k ** 0.5) + torch.finfo(out_dtype).eps * ref.abs().max().item()
     assert (out.cpu().float() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(1, 4096), (5, 11008), (64, 4096), (300, 1024), (4096, 5120)])
+def test_apply_per_channel_scale_direct(cuda, dtype, rows, cols):
+    # the stand-alone smoothing pass (preQuantScaleKernel.cu:26-136 apply_per_channel_scale_kernel_launcher): out = act *
+    # scale[col] in T, one rounding -- bit-exact against the oracle; in place too (the plugin smooths into its workspace)
+    import ctypes as C
+    from mi355q import _lib as L
+    g = torch.Generator().manual_seed(rows + cols)
+    act = torch.randn(rows, cols, generator=g).to(dtype)
+    scale = (torch.rand(1, cols, generator=g) + 0.5).to(dtype)
+    ref = oracle.apply_per_channel_scale(act, scale)
+    d_act, d_scale = act.to(cuda), scale.to(cuda)
+    out = torch.zeros_like(d_act)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = L.HALF if dtype == torch.float16 else L.BF16
+    L.check(L.lib().mi355q_apply_per_channel_scale(out.data_ptr(), d_act.data_ptr(), d_scale.data_ptr(), rows, cols, code, stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    L.check(L.lib().mi355q_apply_per_channel_scale(d_act.data_ptr(), d_act.data_ptr(), d_scale.data_ptr(), rows, cols, code, stream))
+    torch.cuda.synchronize()
+    assert torch.equal(d_act.cpu().view(torch.int16), ref.view(torch.int16))
