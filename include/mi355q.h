@@ -406,8 +406,7 @@ extern "C"
          * relative_attention_bias / relative_attention_bias_stride / max_distance, Template.h:1469-1476, 1773-1797,
          * 1960-1985, 2026): act_type values added to the scaled scores.  max_distance == 0: the explicit tensor
          * [num_heads, stride, stride], entry [h][kv length][t]; max_distance > 0: the table [num_heads, stride = num_buckets]
-         * and the bucket of (t - kv length) computed on the fly.  NULL otherwise.  Generation only (the context phase
-         * with a relative bias is not built). */
+         * and the bucket of (t - kv length) computed on the fly.  NULL otherwise. */
         const void* relative_attention_bias;
         int32_t relative_attention_bias_stride;
         int32_t max_distance;
@@ -476,6 +475,17 @@ extern "C"
          * embedding (k_to_cache = POS_SHIFT ? k_wo_pos : k, unfusedAttentionKernels_2_template.h:284-347), for
          * generation steps with mi355q_decode_attention_params.position_shift_enabled */
         int32_t position_shift_enabled;
+        /* relative attention bias (position_embedding_type 5, kRELATIVE; invokeAddRelativeAttentionBiasUnaligned,
+         * unfusedAttentionKernels.cu:1688-1751, called with bidirectional = false from gptAttentionCommon.cpp:1006-1016
+         * on the scores already scaled by qk_scale, :816-817): T values added to the scaled scores.  max_distance == 0:
+         * the explicit tensor [num_heads, stride, stride], entry [h][query position][key position] (the reference indexes it with
+         * cyclic_attention_window_size as the row length, which is the tensor's own for every consistent caller; the
+         * plugin passes the tensor's dims.d[1]); max_distance > 0: the table
+         * [num_heads, stride = num_buckets] and the one-directional bucket of (query position - key position) computed
+         * on the fly.  NULL otherwise. */
+        const void* relative_attention_bias;
+        int32_t relative_attention_bias_stride;
+        int32_t max_distance;
     } mi355q_context_attention_params;
     size_t mi355q_context_attention_workspace_size(const mi355q_context_attention_params* params);
     mi355q_status mi355q_context_attention(const mi355q_context_attention_params* params, void* stream);

@@ -503,6 +503,20 @@ def relative_bucket_mmha(relative_position, num_buckets, max_distance):
     return rb + min(large, nb - 1)
 
 
+def relative_bucket_unidirectional(relative_position, num_buckets, max_distance):
+    """The bucket of key position - query position as the context phase computes it (addRelativeAttentionBiasUnaligned
+    with bidirectional = false, unfusedAttentionKernels.cu:1703-1727): keys after the query share bucket 0, num_buckets
+    is not halved; fp32 like the kernel."""
+    rp = max(-relative_position, 0)
+    max_exact = num_buckets // 2
+    if rp < max_exact:
+        return rp
+    large = max_exact + int(np.float32(np.log(np.float32(rp) / np.float32(max_exact)))
+                            / np.float32(np.log(np.float32(max_distance) / np.float32(max_exact)))
+                            * np.float32(num_buckets - max_exact))
+    return min(large, num_buckets - 1)
+
+
 def decode_attention(qkv, cache, seq_lens, num_heads, num_kv_heads, head_dim, q_scaling=1.0, rope=None,
                      rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None, kv_scale_orig_quant=1.0,
                      kv_scale_quant_orig=1.0, update_cache=True, alibi_slopes=None, relative_attention_bias=None,
@@ -713,7 +727,8 @@ def apply_rope_rows(x, positions, rot_dim, kind, base=10000.0, scale=1.0):
 
 def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_dim, cache=None, q_scaling=1.0,
                       rope=None, rot_dim=0, rope_base=10000.0, rope_scale=1.0, qkv_bias=None,
-                      kv_scale_orig_quant=1.0, past_lens=None, window=None, cmap=None, alibi_slopes=None, pos_shift=False):
+                      kv_scale_orig_quant=1.0, past_lens=None, window=None, cmap=None, alibi_slopes=None, pos_shift=False,
+                      relative_attention_bias=None, max_distance=0):
     """The context phase of GPTAttention (gptAttentionCommon.cpp:641-1133 enqueueContext), restated:
       * per input token: bias add in T, RoPE at the token's position in its sequence, rounded to T
         (invokeApplyBiasRopeUpdateKVCache / invokeAddFusedQKVBiasTranspose, unfusedAttentionKernels.cu);
@@ -731,7 +746,10 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
         their cyclic slots (unfusedAttentionKernels_2_template.h:336-340);
       * alibi_slopes [Hq] in T: score += slope[h] * (t - a) (unfusedAttentionKernels.cu:212-218);
       * pos_shift (position_shift_enabled): the attention is unchanged, the cache receives K without the rotation
-        (k_to_cache = POS_SHIFT ? k_wo_pos : k, unfusedAttentionKernels_2_template.h:284-347).
+        (k_to_cache = POS_SHIFT ? k_wo_pos : k, unfusedAttentionKernels_2_template.h:284-347);
+      * relative_attention_bias (kRELATIVE; invokeAddRelativeAttentionBiasUnaligned, unfusedAttentionKernels.cu:1688-1751,
+        on the scaled scores, gptAttentionCommon.cpp:816-817, 1006-1016): max_distance == 0: [Hq, S', S'] in T, entry
+        [h][a][t]; max_distance > 0: the table [Hq, num_buckets] and relative_bucket_unidirectional(t - a).
     qkv_rows: list of torch [len_b, (Hq+2Hkv)*Dh] in T, one per sequence.  Returns a list of [len_b, Hq*Dh] in T.
     Tolerance parity like decode_attention (the reference rounds P to T before P.V).  No test of the reference covers
     chunked context, the sliding window or ALiBi in the context phase: those three are "parity unpinned"."""
@@ -783,6 +801,14 @@ def context_attention(qkv_rows, context_lengths, num_heads, num_kv_heads, head_d
             logits = (q[:, h] @ k[:, hk].t()).float() * inv_sqrt
             if alibi_slopes is not None:
                 logits = logits + alibi_slopes[h].float() * (tk - tq).float()
+            if relative_attention_bias is not None:
+                if max_distance > 0:
+                    nb = relative_attention_bias.shape[1]
+                    idx = torch.tensor([[relative_bucket_unidirectional(t - int(a), nb, max_distance) for t in range(kv_len)]
+                                        for a in pos], dtype=torch.long)
+                    logits = logits + relative_attention_bias[h][idx].float()
+                else:
+                    logits = logits + relative_attention_bias[h, past:kv_len, :kv_len].float()
             logits = logits.masked_fill(~mask, float("-inf"))
             p = torch.exp(logits - logits.max(dim=1, keepdim=True).values)
             out[:, h] = (p.double() @ v[:, hk]).float() / (p.sum(dim=1, keepdim=True) + 1e-6)

@@ -95,6 +95,11 @@ struct CtxArgs
     int mask_window;          // sliding window: key t is visible to the query at position a iff a - mask_window <= t <= a
     int kv_window, sink, bubble, cyc_len; // cache slot map of the append (kvCacheUtils.h:71-117); identity without a window
     const uint16_t* alibi_slopes;         // T [Hq] or null: score += slope[h] * (t - a)
+    // relative attention bias (kRELATIVE; invokeAddRelativeAttentionBiasUnaligned, unfusedAttentionKernels.cu:1688-1751,
+    // called with bidirectional = false from gptAttentionCommon.cpp:1006-1016): T values added to the scaled scores.
+    // max_distance == 0: [Hq, rel_stride, rel_stride], entry [h][a][t]; > 0: the table [Hq, rel_stride = num_buckets]
+    const uint16_t* rel_bias;
+    int rel_stride, max_distance;
     int dh_pad; // row length of `proc`: head_size, or the 64 / 128 it is padded to (zeros) for the attention kernel
     int raw_k_cache; // POS_SHIFT: K goes to the cache without the position embedding (k_wo_pos,
                      // unfusedAttentionKernels_2_template.h:284-347); generic prepare kernel only
@@ -433,9 +438,10 @@ constexpr int CTX_QW = 32;   // query rows per wave
 // grid (Hq, ceil(max_len / (32 NWV)), B), block 64 NWV.  blockIdx.y counts query tiles from the END of the sequence so the
 // long (many key tiles) workgroups are dispatched first.
 // CACHED: K / V of keys 0 .. kv_len - 1 come from the (16-bit) cache, the query rows sit at positions past .. (chunked
-// context); else from the workspace rows of this call (past = 0).  BIAS: ALiBi, scores biased before the softmax.
+// context); else from the workspace rows of this call (past = 0).  BIAS 1: ALiBi, 2: relative attention bias; the
+// scores are biased before the softmax.
 // W32: the 32x32x16 MFMA form (lane = one query column of the wave's 32, see compute32 below); else 16x16x32.
-template <typename T, int DH, int NWV, bool CACHED, bool BIAS, bool W32 = false>
+template <typename T, int DH, int NWV, bool CACHED, int BIAS, bool W32 = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 128 ? 1 : 2))) void ctx_attn_kernel(CtxArgs p)
 {
     constexpr int CTX_QB = CTX_QW * NWV;    // query rows per workgroup: 128 (4 waves, short sequences) / 256 (8 waves)
@@ -609,8 +615,27 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
     // BIAS: the scores are scaled and biased in place (log2 domain), the softmax then runs with scale 1
     const float sscale = BIAS ? 1.f : sscale_in;
     float slope2 = 0.f;
-    if constexpr (BIAS)
+    if constexpr (BIAS == 1)
         slope2 = T16<T>::to_float(p.alibi_slopes[h]) * 1.4426950408889634f;
+    // BIAS 2: the bias of (query position a, key t), log2 domain.  Implicit: the decoder's (one-directional) bucket of
+    // a - t, the same float expression as the reference's kernel; explicit: indices clamped to the tensor (entries past
+    // it only ever belong to masked keys or rows that are not stored)
+    auto rel_bias_at = [&](int a, int t) -> float
+    {
+        size_t idx;
+        if (p.max_distance > 0)
+        {
+            const int nb = p.rel_stride, max_exact = nb / 2;
+            const int rp = max(a - t, 0);
+            int large = max_exact
+                + (int) (logf(rp * 1.0f / max_exact) / logf((float) p.max_distance / max_exact) * (nb - max_exact));
+            large = min(large, nb - 1);
+            idx = (size_t) h * nb + (rp < max_exact ? rp : large);
+        }
+        else
+            idx = ((size_t) h * p.rel_stride + min(a, p.rel_stride - 1)) * p.rel_stride + min(t, p.rel_stride - 1);
+        return T16<T>::to_float(p.rel_bias[idx]) * 1.4426950408889634f;
+    };
 
     float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
     cf32x4_t o[W32 ? 1 : 2][W32 ? 1 : DT];
@@ -668,13 +693,21 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
             for (int qt = 0; qt < 2; ++qt)
             {
                 const int qpos = past + q0 + 16 * qt + lr;
-                if constexpr (BIAS)
+                if constexpr (BIAS == 1)
                 {
     #pragma unroll
                     for (int x = 0; x < 4; ++x)
     #pragma unroll
                         for (int rr = 0; rr < 4; ++rr)
                             s[x][qt][rr] = __builtin_fmaf(s[x][qt][rr], sscale_in, slope2 * (float) (t0 + 16 * x + 4 * lq + rr - qpos));
+                }
+                if constexpr (BIAS == 2)
+                {
+    #pragma unroll
+                    for (int x = 0; x < 4; ++x)
+    #pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            s[x][qt][rr] = __builtin_fmaf(s[x][qt][rr], sscale_in, rel_bias_at(qpos, t0 + 16 * x + 4 * lq + rr));
                 }
                 if (need_mask)
                 {
@@ -780,7 +813,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
             const bool need_mask = t0 + CTX_KT - 1 > past + q0 || t0 + CTX_KT > kv_len
                 || t0 < past + q0 + CTX_QW - 1 - window; // wave-uniform: diagonal, end of the sequence, start of a row's window
             const int qpos = past + q0 + L;
-            if constexpr (BIAS)
+            if constexpr (BIAS == 1)
             {
 #pragma unroll
                 for (int x2 = 0; x2 < 2; ++x2)
@@ -788,6 +821,15 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
                     for (int i = 0; i < 16; ++i)
                         s[x2][i] = __builtin_fmaf(
                             s[x2][i], sscale_in, slope2 * (float) (t0 + 32 * x2 + 8 * (i >> 2) + 4 * hh + (i & 3) - qpos));
+            }
+            if constexpr (BIAS == 2)
+            {
+#pragma unroll
+                for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s[x2][i] = __builtin_fmaf(
+                            s[x2][i], sscale_in, rel_bias_at(qpos, t0 + 32 * x2 + 8 * (i >> 2) + 4 * hh + (i & 3)));
             }
             if (need_mask)
             {
@@ -1053,8 +1095,24 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
             "rotary_embedding_dim %d", q.rotary_embedding_dim);
     else if (q.position_embedding_type == 3 || q.position_embedding_type == 4) // kALIBI / kALIBI_WITH_SCALE: the scale is in the slopes
         MQ_CHECK(q.alibi_slopes, "position_embedding_type %d needs alibi_slopes", q.position_embedding_type);
+    else if (q.position_embedding_type == 5) // kRELATIVE
+    {
+        MQ_CHECK(q.relative_attention_bias && q.relative_attention_bias_stride > 0 && q.max_distance >= 0,
+            "position_embedding_type 5 needs relative_attention_bias (stride %d, max_distance %d)",
+            q.relative_attention_bias_stride, q.max_distance);
+        if (q.max_distance > 0) // max_exact = num_buckets / 2 divides inside a logarithm
+            MQ_CHECK(q.relative_attention_bias_stride >= 2, "implicit relative attention bias with %d buckets",
+                q.relative_attention_bias_stride);
+        else
+            MQ_CHECK(q.relative_attention_bias_stride >= max_kv,
+                "the relative attention bias [heads, %d, %d] does not cover kv length %d", q.relative_attention_bias_stride,
+                q.relative_attention_bias_stride, max_kv);
+        a.rel_bias = reinterpret_cast<const uint16_t*>(q.relative_attention_bias);
+        a.rel_stride = q.relative_attention_bias_stride;
+        a.max_distance = q.max_distance;
+    }
     else
-        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in context (0 - 4)",
+        MQ_CHECK(q.position_embedding_type == 0, "position_embedding_type %d not supported in context (0 - 5)",
             q.position_embedding_type);
     const size_t hidden = (size_t) (q.num_heads + 2 * q.num_kv_heads) * q.head_size;
     const size_t hidden_pad = (size_t) (q.num_heads + 2 * q.num_kv_heads) * dh_pad;
@@ -1081,7 +1139,8 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     MQ_CHECK(plds <= 64 * 1024, "qkv hidden size %zu too large for the prepare kernel", hidden);
     const bool fast = !a.raw_k_cache && dh_pad == q.head_size && q.head_size <= 128 // (the fast kernel's cos / sin table holds 64 pairs)
         && (q.position_embedding_type == 0 || q.position_embedding_type == 1 || q.position_embedding_type == 3
-            || q.position_embedding_type == 4 || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size));
+            || q.position_embedding_type == 4 || q.position_embedding_type == 5
+            || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size));
     if (fast && bf)
         hipLaunchKernelGGL(ctx_prepare_fast_kernel<bf16_t>, pgrid, dim3(256), 0, stream, a);
     else if (fast)
@@ -1093,7 +1152,7 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     // 4 waves x 32 query rows per workgroup.  (8-wave workgroups -- lock-stepped, or the two halves run one segment
     // apart so that a SIMD's two waves alternate matrix and VALU segments -- measured 3-8 % slower: DESIGN.md 4.4)
     const dim3 agrid(q.num_heads, (q.max_context_length + 32 * 4 - 1) / (32 * 4), q.batch);
-    const bool bias = a.alibi_slopes != nullptr;
+    const int bias = a.rel_bias ? 2 : a.alibi_slopes ? 1 : 0;
 #ifdef MI355Q_LAB
     // lab: the 32x32x16 form of the same kernel (measured: within -3 .. +3 % of the 16x16x32 form)
     const bool w32 = lab_env("MI355Q_CTX_W32") != nullptr && dh_pad <= 128;
@@ -1111,14 +1170,18 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
 #define MQ_CTX_LAUNCH(TT, DD)                                                                                          \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (cached && bias)                                                                                            \
-            MQ_CTX_LAUNCH2(TT, DD, true, true);                                                                        \
+        if (cached && bias == 2)                                                                                       \
+            MQ_CTX_LAUNCH2(TT, DD, true, 2);                                                                           \
+        else if (cached && bias)                                                                                       \
+            MQ_CTX_LAUNCH2(TT, DD, true, 1);                                                                           \
         else if (cached)                                                                                               \
-            MQ_CTX_LAUNCH2(TT, DD, true, false);                                                                       \
+            MQ_CTX_LAUNCH2(TT, DD, true, 0);                                                                           \
+        else if (bias == 2)                                                                                            \
+            MQ_CTX_LAUNCH2(TT, DD, false, 2);                                                                          \
         else if (bias)                                                                                                 \
-            MQ_CTX_LAUNCH2(TT, DD, false, true);                                                                       \
+            MQ_CTX_LAUNCH2(TT, DD, false, 1);                                                                          \
         else                                                                                                           \
-            MQ_CTX_LAUNCH2(TT, DD, false, false);                                                                      \
+            MQ_CTX_LAUNCH2(TT, DD, false, 0);                                                                          \
     } while (0)
     if (bf && dh_pad == 256)
         MQ_CTX_LAUNCH(bf16_t, 256);

@@ -1428,8 +1428,8 @@ struct GPTAttentionPlugin : PluginBase
         MQ_CHECK(seqBeg == 0 && tokenBeg == 0, "context requests come first");
         if (f.mask_type != 1)
             MQ_UNSUPPORTED("GPTAttention context: only the causal mask (AttentionMaskType::CAUSAL = 1) is built, got %d", f.mask_type);
-        if (f.position_embedding_type < 0 || f.position_embedding_type > 4)
-            MQ_UNSUPPORTED("GPTAttention context: position_embedding_type %d is not built (0 - 4)", f.position_embedding_type);
+        if (f.position_embedding_type < 0 || f.position_embedding_type > 5)
+            MQ_UNSUPPORTED("GPTAttention context: position_embedding_type %d is not built (0 - 5)", f.position_embedding_type);
         const auto& qkvDims = inDesc[getIdx(QKV_TENSOR)].dims;
         int max_len;
         if (f.remove_input_padding)
@@ -1467,8 +1467,12 @@ struct GPTAttentionPlugin : PluginBase
         c.qkv_bias = f.qkv_bias_enabled ? inputs[getIdx(QKV_BIAS_TENSOR)] : nullptr;
         if (f.position_embedding_type == 3 || f.position_embedding_type == 4)
             c.alibi_slopes = inputs[getIdx(ALIBI_SLOPES)];
-        if (f.position_embedding_type == 5)
-            MQ_UNSUPPORTED("GPTAttention context phase with a relative attention bias is not built (generation is)");
+        if (f.position_embedding_type == 5) // isRelativePosition(), gptAttentionPlugin.cpp:590-596; gptAttentionCommon.cpp:1006-1016
+        {
+            c.relative_attention_bias = inputs[getIdx(RELATIVE_ATTENTION_BIAS)];
+            c.relative_attention_bias_stride = inDesc[getIdx(RELATIVE_ATTENTION_BIAS)].dims.d[1]; // max_seq_len or num_buckets
+            c.max_distance = f.max_distance;
+        }
         c.out = outputs[0];
         c.context_lengths = static_cast<const int32_t*>(inputs[getIdx(CONTEXT_LENGTHS)]) + seqBeg;
         c.workspace = workspace;

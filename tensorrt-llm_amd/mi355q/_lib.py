@@ -129,6 +129,7 @@ class ContextAttentionParams(C.Structure):
         ("cyclic_attention_window_size", C.c_int32), ("sink_token_length", C.c_int32),
         ("alibi_slopes", C.c_void_p),
         ("position_shift_enabled", C.c_int32),
+        ("relative_attention_bias", C.c_void_p), ("relative_attention_bias_stride", C.c_int32), ("max_distance", C.c_int32),
     ]
 
 

@@ -42,12 +42,12 @@ def block_table(cache, pool, num_layers, layer_idx):
 
 
 def run_context(plg, rows, cache, pool, dev, kv_scale, remove_padding, bias=None, num_layers=1, layer_idx=0,
-                gen_rows=None, gen_seq_lens=None):
+                gen_rows=None, gen_seq_lens=None, **extra):
     """Enqueue the plugin with len(rows) context requests (+ optional generation requests after them)."""
     lens = [r.shape[0] for r in rows]
     nctx, ngen = len(rows), 0 if gen_rows is None else gen_rows.shape[0]
     B = nctx + ngen
-    hidden = rows[0].shape[1]
+    hidden = (rows[0] if rows else gen_rows).shape[1]
     if remove_padding:
         parts = list(rows) + ([gen_rows] if ngen else [])
         qkv = torch.cat(parts, 0).to(dev)
@@ -76,11 +76,12 @@ def run_context(plg, rows, cache, pool, dev, kv_scale, remove_padding, bias=None
         kwargs["host_context_lengths"] = ctx
     if bias is not None:
         kwargs["qkv_bias"] = bias.to(dev)
+    kwargs.update(extra)
     out = F.gpt_attention(plg, **kwargs)
     torch.cuda.synchronize()
     out = out.cpu()
     if remove_padding:
-        offs = np.concatenate([[0], np.cumsum(lens)])
+        offs = [0] + [int(v) for v in np.cumsum(lens)]
         outs = [out[offs[b]:offs[b + 1]] for b in range(nctx)]
         gen_out = out[offs[-1]:] if ngen else None
     else:
@@ -139,6 +140,48 @@ def test_context_8bit_cache(cuda, dtype, kv_dtype):
 def test_context_rope_and_bias(cuda, dtype, rope):
     check([77, 300], 8, 2, 128, 64, dtype, dtype, cuda, rope=rope, with_bias=True)
     check([77, 300], 4, 4, 64, 64, dtype, torch.int8, cuda, rope=rope)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D,kv_dtype", [(4, 4, 64, None), (8, 2, 128, torch.int8), (6, 2, 32, None)])
+def test_context_relative_attention_bias(cuda, dtype, Hq, Hkv, D, kv_dtype):
+    # kRELATIVE (5) in the context phase: the bias is added to the scaled scores before the masked softmax
+    # (gptAttentionCommon.cpp:816-817, 1006-1016; addRelativeAttentionBiasUnaligned, unfusedAttentionKernels.cu:1688-1737,
+    # bidirectional = false).  Explicit tensor [Hq, S', S'] (max_distance 0) and the implicit bucket table [Hq, num_buckets]
+    # (max_distance 128); then ONE generation step of every sequence with the same bias input, over the cache this call
+    # appended.  The reference's attention test has no relative-bias case for this plugin: "parity unpinned", the oracle
+    # restates the cited lines.
+    kv_dtype = kv_dtype or dtype
+    lens, tpb, dev = [150, 9, 333], 64, cuda
+    kv_scale = 4.0 / 127.0 if kv_dtype == torch.int8 else 1.0
+    qs = 1.0 / np.sqrt(D)  # score = q.k itself
+    g = torch.Generator().manual_seed(5)
+    for max_distance, shape in ((0, (Hq, 384, 384)), (128, (Hq, 32))):
+        rel = (torch.randn(shape, generator=g) * 0.7).to(dtype)
+        rows = [(r.float() * 0.3).to(dtype) for r in make_inputs(lens, Hq, Hkv, D, dtype, seed=max_distance + 3)]
+        cache = oracle.PagedKVCache(len(lens), Hkv, D, max(lens) + 24, tpb, kv_dtype, seed=1)
+        pool = cache.pool.to(dev)
+        plg = F.make_gpt_attention_plugin(
+            num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="float16" if dtype == torch.float16 else "bfloat16",
+            position_embedding_type=5, kv_cache_quant_mode=QM.get(kv_dtype, 0), paged_kv_cache=True, tokens_per_block=tpb,
+            max_distance=max_distance, q_scaling=qs, remove_input_padding=True)
+        outs, _ = run_context(plg, rows, cache, pool, dev, kv_scale, True, relative_attention_bias=rel.to(dev))
+        refs = oracle.context_attention(rows, lens, Hq, Hkv, D, cache=cache, q_scaling=qs, kv_scale_orig_quant=1.0 / kv_scale,
+                                        relative_attention_bias=rel, max_distance=max_distance)
+        plain = oracle.context_attention(rows, lens, Hq, Hkv, D, q_scaling=qs)
+        for b, (o, r) in enumerate(zip(outs, refs)):
+            err = (o.float() - r.float()).abs().max().item()
+            assert err <= ATOL[dtype], f"max_distance {max_distance}, sequence {b}: max abs err {err}"
+        assert max((p.float() - r.float()).abs().max().item() for p, r in zip(plain, refs)) > 5 * ATOL[dtype]  # the bias matters here
+        compare_cache(pool.cpu(), cache, None)
+        # the generation step that follows
+        gen = (torch.randn(len(lens), (Hq + 2 * Hkv) * D, generator=g) * 0.15).to(dtype)
+        seq = [n + 1 for n in lens]
+        _, gout = run_context(plg, [], cache, pool, dev, kv_scale, True, gen_rows=gen, gen_seq_lens=seq,
+                              relative_attention_bias=rel.to(dev))
+        gref = oracle.decode_attention(gen, cache, seq, Hq, Hkv, D, q_scaling=qs, kv_scale_orig_quant=1.0 / kv_scale,
+                                       kv_scale_quant_orig=kv_scale, relative_attention_bias=rel, max_distance=max_distance)
+        assert (gout.float() - gref.float()).abs().max().item() <= ATOL[dtype]
 
 
 def test_context_partial_rotary(cuda):
