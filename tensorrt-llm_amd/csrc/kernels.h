@@ -57,6 +57,9 @@ int woq_prefill_ksplit(int m, int n, int k, int weight_type);
 void woq_splitk_reduce(const float* slabs, const void* bias, const float* alpha, void* out, int m, int n, int ksplit,
     bool bf16, hipStream_t stream);
 void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream);
+// the skinny form (16 < m <= 64, one burst per workgroup, split-K closed inside the launch); false = does not apply
+size_t woq_skinny_workspace_size(int m, int n, int k, int weight_type);
+bool weight_only_skinny_gemm(const WoqArgsHost& h, void* workspace, size_t workspace_bytes, hipStream_t stream);
 void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream);
 size_t moe_workspace_size(const mi355q_moe_params& p);
 void run_moe(const mi355q_moe_params& p, hipStream_t stream);

@@ -86,12 +86,15 @@ __host__ __device__ constexpr int gemv_s1_floats(int krange, int mc)
 //     P  = sum_k a[m,k] * u[k,n]      (MFMA, u = q + 8 exact in 16 bits, fp32 accumulate)
 //     S1 = sum_k a[m,k]               (depends on the activations only: summed once per block while they are staged,
 //                                      `s1frag(mc, h)` reads the lane's 4 rows of it from LDS)
-//     acc += scale * P + (zero - 8 * scale) * S1   ==   sum_k a * (q * scale + zero)
-// i.e. the scale / zero are applied to the group's partial sums (8-9 VALU ops per group) instead of
+//     acc += scale * (P - 8 * S1) + zero * S1   ==   sum_k a * (q * scale + zero)
+// i.e. the scale / zero are applied to the group's partial sums (12 VALU ops per group) instead of
 // to every weight.  Unlike kernel.h:364-365 / mma_tensorop_dequantizer.h the dequantised weight is
-// not rounded to 16 bits before the multiply, so results differ from the exact-dequant path by
-// about half an output ulp (closer to the real-number result); mi355q_weight_only_dequantize and
-// the prefill GEMM keep the bit-exact rounding.
+// not rounded to 16 bits before the multiply, so for general activations results differ from the
+// exact-dequant path by about half an output ulp (closer to the real-number result).  Written in this
+// order -- not as scale * P + (zero - 8 * scale) * S1, whose second factor is rounded -- a one-hot
+// activation row gives P - 8 S1 = q and zero * S1 = zero exactly, i.e. fma(q, scale, zero) itself:
+// the reference's identity-activation gate (test_weight_only_quant_matmul.py:44-53) recovers the
+// dequantised weights bit for bit through this kernel too.
 template <typename T, int NSZ, int STEPS, int MC, typename AF, typename SF>
 __device__ __forceinline__ void gemv_tile_int4(
     const uint4& w, f32x4_t (&acc)[MC], const float* s, const float* z, AF afrag, SF s1frag)
@@ -113,14 +116,13 @@ __device__ __forceinline__ void gemv_tile_int4(
             for (int mc = 0; mc < MC; ++mc)
                 P[mc] = mfma16<T>(afrag(mc, st), u, P[mc]);
         }
-        const float zc = fmaf(-8.f, s[h], z[h]);
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
         {
             const f32x4_t S1 = s1frag(mc, h);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[mc][r] = fmaf(zc, S1[r], fmaf(s[h], P[mc][r], acc[mc][r]));
+                acc[mc][r] = fmaf(s[h], fmaf(-8.f, S1[r], P[mc][r]), fmaf(z[h], S1[r], acc[mc][r]));
         }
     }
 }
@@ -823,6 +825,8 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
                 continue;
             }
         }
+        if (!woq_gemm_fuses_act_scale(mm, n, k))
+            best = std::max(best, woq_skinny_workspace_size(mm, n, k, weight_type));
         const int s = !woq_gemm_fuses_act_scale(mm, n, k) ? woq_prefill_ksplit(mm, n, k, weight_type)
                                                                              : woq_choose_ksplit(mm, n, k, weight_type);
         if (s > 1)
@@ -867,6 +871,8 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
         float* slabs = (ks > 1 && workspace && workspace_bytes >= need) ? reinterpret_cast<float*>(workspace) : nullptr;
         WoqArgsHost h{a.qweight, a.scales, a.zeros, a.act, a.bias, a.out, a.m, a.n, a.k, a.group, a.group_shift, a.ktiles,
             p.act_type == MI355Q_BF16, p.weight_type == MI355Q_WEIGHT_INT4, slabs, a.alpha};
+        if (weight_only_skinny_gemm(h, workspace, workspace_bytes, stream)) // m <= 64: one burst per workgroup
+            return;
         weight_only_prefill_gemm(h, stream);
         if (slabs)
             woq_splitk_reduce(slabs, p.bias, p.alpha, p.out, p.m, p.n, ks, p.act_type == MI355Q_BF16, stream);

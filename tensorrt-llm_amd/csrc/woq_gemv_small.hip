@@ -124,8 +124,9 @@ __device__ __forceinline__ void light_mma(const uint4& wf, const uint4* act, f32
 //   int8: exact dequantisation w = round16(fma(q, s, z)) of the lane's 8 weights, then the MFMA(s);
 //   int4: the integer domain of woq_gemm.hip (gemv_tile_int4): P = sum a * u on the MFMA with u = q + 8 unpacked exactly
 //         through the fp8 converter (7 VALU operations per 8 weights instead of 23), S1 = sum a through the same MFMA
-//         against ones, then acc += s * P + (z - 8 s) * S1 == sum a * (q s + z): the weight is not rounded to 16 bits
-//         before the multiply (results within half an output ulp of the rounded-weight result).
+//         against ones, then acc += s * (P - 8 S1) + z * S1 == sum a * (q s + z): the weight is not rounded to 16 bits
+//         before the multiply (results within half an output ulp of the rounded-weight result; a one-hot activation
+//         row gives fma(q, s, z) exactly, see gemv_tile_int4).
 template <typename T, int WBITS, int MF, int ST, int N>
 __device__ __forceinline__ void light_group(const uint4& w, float s, float z, const uint4* act, f32x4_t* acc)
 {
@@ -154,12 +155,11 @@ __device__ __forceinline__ void light_group(const uint4& w, float s, float z, co
             light_mma<T, MF, ST + 3>(unpack8_u4<T>(wd[ST + 3]), act, P);
             light_mma<T, MF, ST + 3>(ones, act, S1);
         }
-        const float zc = fmaf(-8.f, s, z);
 #pragma unroll
         for (int ps = 0; ps < (MF == 1 ? 2 : 1); ++ps)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[ps][r] = fmaf(zc, S1[ps][r], fmaf(s, P[ps][r], acc[ps][r]));
+                acc[ps][r] = fmaf(s, fmaf(-8.f, S1[ps][r], P[ps][r]), fmaf(z, S1[ps][r], acc[ps][r]));
     }
 }
 

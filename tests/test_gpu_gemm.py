@@ -112,6 +112,17 @@ def test_groupwise_two_row_chunks_large_k(cuda, m):
     _groupwise_case(m, 2048, 8192, "bfloat16", False, True, True, 128, cuda)
 
 
+@pytest.mark.parametrize("m,n,k,pre,zero,bias,gs,dtype_str", [
+    (64, 3584, 8192, False, True, False, 128, "bfloat16"), (33, 1280, 8192, True, True, True, 128, "float16"),
+    (40, 1024, 4096, False, False, True, 64, "bfloat16"), (64, 8192, 1024, False, True, True, 64, "float16"),
+    (49, 2560, 2048, True, False, False, 128, "bfloat16"), (64, 128, 128, False, True, True, 128, "float16")])
+def test_groupwise_skinny_form(cuda, m, n, k, pre, zero, bias, gs, dtype_str):
+    # 32 < m <= 64 at decode-sized weights (the tensor-parallel slices of cfg4 at a few dozen sequences): the skinny form
+    # of the GEMM -- one burst of loads per workgroup, integer-domain int4 arithmetic, split-K closed inside the launch
+    # (woq_skinny_kernel).  Ragged last m-block, both group sizes, 1 .. 16 pieces per tile, one-piece tiles (no partials)
+    _groupwise_case(m, n, k, dtype_str, pre, zero, bias, gs, cuda)
+
+
 @pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
 @pytest.mark.parametrize("m,n,k,pre,zero,bias,gs", [(512, 32768, 256, False, True, False, 128),
                                                     (300, 32768, 320, True, True, True, 64),
