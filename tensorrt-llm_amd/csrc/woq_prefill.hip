@@ -138,9 +138,15 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
 // wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).  At
 // MT = 4 the ring's 64 KiB of LDS leave 2 workgroups per CU where the ping-pong has 5, and the ping-pong wins (grouped
 // MoE launch, 64 rows per expert: 167 against 192 us, tools/lab_moe_depth.py).
-template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2, int NW = PF_WAVES>
+// INTD (int4, the 32-row tiles of a weight stream -- the grouped MoE launch at decode): the integer domain of the
+// decode GEMV (gemv_tile_int4, woq_gemm.hip).  At MT = 2 a dequantised fragment feeds two MFMAs and the exact
+// dequantisation's 23 vector-ALU operations per 8 weights are the bound, next to HBM; here the nibbles go to the
+// MFMA as u = 0 .. 15 (7 operations per 8 weights) and scale / zero meet the accumulator once per group,
+// acc += s (P - 8 S1) + z S1 with S1 = sum a from one more MFMA against ones per (k-step, m-block).
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2, int NW = PF_WAVES, bool INTD = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
 {
+    static_assert(!INTD || WBITS == 4, "integer domain: int4 weights");
     constexpr int PF_TN = NB * 16 * NW;
     constexpr int KTILE = Geo<WBITS>::KTILE;   // 128 (int4) / 64 (int8) rows of k per weight tile
     constexpr int KSTEPS = Geo<WBITS>::KSTEPS; // MFMA k-steps per tile
@@ -251,7 +257,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     struct WTile
     {
         uint4 w[NB];
-        uint32_t s[NB][NSZ], z[NB][NSZ]; // 16-bit values, zero-extended
+        uint32_t s[NB][NSZ], z[NB][NSZ]; // 16-bit values, zero-extended: column lane & 15 (A-operand row)
+        uint2 s4[NB][NSZ], z4[NB][NSZ];  // INTD instead: the lane's four output rows 4 (lane >> 4) .. + 3 (D layout)
     };
     auto load_sz = [&](WTile& t, int kt)
     {
@@ -261,9 +268,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             for (int h = 0; h < NSZ; ++h)
             {
                 const int k = min(kt * KTILE + h * 64, a.k - 1);
-                const size_t si = (size_t) (k >> a.group_shift) * a.n + col0 + b * 16;
-                t.s[b][h] = a.scales[si];
-                t.z[b][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
+                if constexpr (INTD)
+                {
+                    const size_t si = (size_t) (k >> a.group_shift) * a.n + (size_t) (nb0 + b) * 16 + 4 * (lane >> 4);
+                    t.s4[b][h] = *reinterpret_cast<const uint2*>(a.scales + si);
+                    t.z4[b][h] = ZERO ? *reinterpret_cast<const uint2*>(a.zeros + si) : make_uint2(0u, 0u);
+                }
+                else
+                {
+                    const size_t si = (size_t) (k >> a.group_shift) * a.n + col0 + b * 16;
+                    t.s[b][h] = a.scales[si];
+                    t.z[b][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
+                }
             }
     };
     auto load_w = [&](WTile& t, int kt) // a full tile: no branch between the loads
@@ -294,7 +310,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             asm volatile("" : "+v"(t.w[b].x), "+v"(t.w[b].y), "+v"(t.w[b].z), "+v"(t.w[b].w));
 #pragma unroll
             for (int h = 0; h < NSZ; ++h)
-                asm volatile("" : "+v"(t.s[b][h]), "+v"(t.z[b][h]));
+            {
+                if constexpr (INTD)
+                    asm volatile("" : "+v"(t.s4[b][h].x), "+v"(t.s4[b][h].y), "+v"(t.z4[b][h].x), "+v"(t.z4[b][h].y));
+                else
+                    asm volatile("" : "+v"(t.s[b][h]), "+v"(t.z[b][h]));
+            }
         }
     };
 
@@ -326,7 +347,71 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         __syncthreads();
     }
 
-    auto compute = [&](const WTile& t, int buf, int steps)
+    auto compute_intd = [&](const WTile& t, int buf, int steps)
+    {
+        constexpr int KG = KSTEPS / NSZ; // k-steps per (scale, zero) group
+        const uint8_t* sa = frag_base + buf * BUF_BYTES;
+        const uint4 ones = ones8<T>();
+        pf_static_for<NSZ>(
+            [&](auto hc)
+            {
+                constexpr int h = decltype(hc)::value;
+                if (h * KG >= steps) // the int4 half tile: its second group is past k
+                    return;
+                f32x4_t pacc[NB][MT], s1[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                {
+                    s1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        pacc[b][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+                pf_static_for<KG>(
+                    [&](auto gc)
+                    {
+                        constexpr int st = h * KG + decltype(gc)::value;
+                        uint4 wf[NB];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            wf[b] = unpack8_u4<T>(reinterpret_cast<const uint32_t*>(&t.w[b])[st]);
+                        const int coff = ((st * 4 + fk) ^ fsw) << 4;
+                        constexpr int AF = MT - 1 < 3 ? MT - 1 : 3, R = AF + 1;
+                        const uint32_t abase = (uint32_t) (uintptr_t) (lds_void_t*) sa + (uint32_t) coff;
+                        pf_u32x4_t av[R];
+                        pf_static_for<AF>(
+                            [&](auto jc) { pf_lds_read<decltype(jc)::value * 16 * RB>(av[decltype(jc)::value % R], abase); });
+                        pf_static_for<MT>(
+                            [&](auto jc)
+                            {
+                                constexpr int j = decltype(jc)::value;
+                                if constexpr (j + AF < MT)
+                                    pf_lds_read<(j + AF) * 16 * RB>(av[(j + AF) % R], abase);
+                                constexpr int issued = j + AF < MT ? j + 1 + AF : MT;
+                                pf_lds_wait<issued - (j + 1)>(av[j % R]);
+                                const uint4 af = __builtin_bit_cast(uint4, av[j % R]);
+#pragma unroll
+                                for (int b = 0; b < NB; ++b)
+                                    pacc[b][j] = mfma16<T>(wf[b], af, pacc[b][j]);
+                                s1[j] = mfma16<T>(ones, af, s1[j]);
+                            });
+                    });
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                {
+                    const float sv[4] = {T16<T>::lo(t.s4[b][h].x), T16<T>::hi(t.s4[b][h].x), T16<T>::lo(t.s4[b][h].y),
+                        T16<T>::hi(t.s4[b][h].y)};
+                    const float zv[4] = {T16<T>::lo(t.z4[b][h].x), T16<T>::hi(t.z4[b][h].x), T16<T>::lo(t.z4[b][h].y),
+                        T16<T>::hi(t.z4[b][h].y)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+                            acc[b][j][i] = fmaf(sv[i], fmaf(-8.f, s1[j][i], pacc[b][j][i]), fmaf(zv[i], s1[j][i], acc[b][j][i]));
+                }
+            });
+    };
+    auto compute_exact = [&](const WTile& t, int buf, int steps)
     {
         float s[NB][NSZ], z[NB][NSZ];
 #pragma unroll
@@ -385,6 +470,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
                         acc[b][j] = mfma16<T>(wf[b], af, acc[b][j]);
                 });
         }
+    };
+
+    auto compute = [&](const WTile& t, int buf, int steps)
+    {
+        if constexpr (INTD)
+            compute_intd(t, buf, steps);
+        else
+            compute_exact(t, buf, steps);
     };
 
     // one tile boundary: everything issued for the next tile (DMA and weights) has landed, all waves are done with
@@ -1253,7 +1346,10 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (MTV <= 2 && !lab_env("MI355Q_PF_DEPTH2"))                                                                  \
+        if (MTV <= 2 && WB == 4 && !lab_env("MI355Q_MOE_EXACT"))                                                       \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, (MTV <= 2 && WB == 4)>), \
+                dim3(tiles_m * tiles_n, a.ksplit), dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);               \
+        else if (MTV <= 2 && !lab_env("MI355Q_PF_DEPTH2"))                                                             \
             hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \
                 dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);                                                  \
         else                                                                                                           \
