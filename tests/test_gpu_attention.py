@@ -252,3 +252,56 @@ def test_decode_llama7b_shape_property(cuda):
     assert (got - cvec.float()[None]).abs().max().item() <= 2e-2  # one bf16 ulp at |c| <= 4
     last = pool[perm[:, -1].to(dev), 1, :, tpb - 1].cpu()  # V line of token ctx-1 of every sequence
     assert torch.equal(last, cvec[None].expand(B, H, D))
+
+
+@pytest.mark.parametrize("Hq,Hkv,kv_dtype,label", [(8, 1, torch.int8, "cfg4: Llama-2-70B 64q/8kv int8 KV, the TP = 8 per-GPU slice"),
+                                                   (64, 8, torch.int8, "cfg4 without the split: 64q/8kv int8 KV"),
+                                                   (32, 8, torch.float8_e4m3fn, "cfg5: Mixtral 32q/8kv fp8 KV")])
+def test_decode_gqa_8bit_full_size_property(cuda, Hq, Hkv, kv_dtype, label):
+    # BASELINE cfg4 / cfg5 at full size (batch 64, ctx 2048, d = 128, the MFMA GQA kernel) through the same
+    # size-independent property as cfg2 above: every cached V line of a kv head holds quant(c), so whatever K and q are the
+    # output is a convex mix of dequant(quant(c)) (cached tokens) and c (the new token, still un-quantised in registers);
+    # the appended K / V lines of the new token must equal the oracle's quantisation of them, bit for bit.
+    B, D, ctx, tpb, dt = 64, 128, 2048, 64, torch.bfloat16
+    dev = cuda
+    g = torch.Generator(device="cpu").manual_seed(7)
+    kv_scale = 4.0 / 127.0 if kv_dtype == torch.int8 else 0.5       # dequantisation scale (KV_CACHE_DEQUANTIZATION_SCALE)
+    nblk = B * (ctx // tpb)
+    cvec = torch.randn(Hkv, D, generator=g).to(dt)
+    c8 = oracle.quantize_kv(cvec, kv_dtype, 1.0 / kv_scale)           # [Hkv, D]
+    cq = c8.float() * kv_scale
+    pool = torch.empty(nblk, 2, Hkv, tpb, D, dtype=kv_dtype, device=dev)
+    k8 = oracle.quantize_kv(torch.randn(nblk, Hkv, tpb, D, generator=g) * 0.5, kv_dtype, 1.0 / kv_scale)
+    pool[:, 0] = k8.to(dev)
+    pool[:, 1] = c8.to(dev)[None, :, None, :]
+    perm = torch.randperm(nblk, generator=g).reshape(B, ctx // tpb)
+    be = Hkv * tpb * D                                                # one byte per element
+    ptrs = torch.stack([perm * 2 * be, perm * 2 * be + be], 1) + pool.data_ptr()
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, generator=g).to(dt)
+    qkv[:, (Hq + Hkv) * D:] = cvec.reshape(1, -1)
+    seq = torch.full((B,), ctx, dtype=torch.int32)
+    plg = F.make_gpt_attention_plugin(num_heads=Hq, num_kv_heads=Hkv, head_size=D, dtype="bfloat16", tokens_per_block=tpb,
+                                      kv_cache_quant_mode=(1 << 6) if kv_dtype == torch.int8 else (1 << 7))
+    out = F.gpt_attention(
+        plg, qkv=qkv.to(dev).reshape(B, 1, -1), sequence_length=seq.to(dev), host_past_key_value_lengths=seq - 1,
+        host_max_attention_window_sizes=torch.tensor([ctx], dtype=torch.int32),
+        host_sink_token_length=torch.zeros(1, dtype=torch.int32), context_lengths=(seq - 1).to(dev),
+        cache_indirection=torch.zeros(B, 1, ctx, dtype=torch.int32, device=dev),
+        host_request_types=torch.ones(B, dtype=torch.int32),
+        kv_cache_block_pointers=ptrs.reshape(1, B, 2, -1).to(dev),
+        host_kv_cache_block_pointers=ptrs.reshape(1, B, 2, -1),
+        kv_orig_quant_scale=torch.tensor([1.0 / kv_scale], dtype=torch.float32, device=dev),
+        kv_quant_orig_scale=torch.tensor([kv_scale], dtype=torch.float32, device=dev))
+    torch.cuda.synchronize()
+    got = out.reshape(B, Hq, D).float().cpu()
+    grp = Hq // Hkv
+    ref = cq.repeat_interleave(grp, 0)[None]                          # [1, Hq, D]
+    slack = (cvec.float() - cq).abs().max().item()                    # the new token's share pulls towards c
+    assert (got - ref).abs().max().item() <= slack + 3e-2, label
+    # the new token's lines at position ctx - 1
+    last = perm[:, -1].to(dev)
+    v_line = pool[last, 1, :, tpb - 1].cpu()
+    assert torch.equal(v_line.view(torch.uint8), c8[None].expand(B, Hkv, D).contiguous().view(torch.uint8)), label
+    k_new = qkv[:, Hq * D:(Hq + Hkv) * D].reshape(B, Hkv, D)
+    k_line = pool[last, 0, :, tpb - 1].cpu()
+    assert torch.equal(k_line.view(torch.uint8), oracle.quantize_kv(k_new, kv_dtype, 1.0 / kv_scale).view(torch.uint8)), label
