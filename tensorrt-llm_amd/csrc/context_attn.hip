@@ -101,6 +101,8 @@ struct CtxArgs
     const uint16_t* rel_bias;
     int rel_stride, max_distance;
     int dh_pad; // row length of `proc`: head_size, or the 64 / 128 it is padded to (zeros) for the attention kernel
+    int kv_from_cache; // the attention kernel reads K / V from the cache this call appends to (16-bit cache, every token at its
+                       // own slot): the fast prepare kernel then writes K / V once, not to the workspace as well
     int raw_k_cache; // POS_SHIFT: K goes to the cache without the position embedding (k_wo_pos,
                      // unfusedAttentionKernels_2_template.h:284-347); generic prepare kernel only
 };
@@ -371,9 +373,12 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
         }
         const uint4 o0 = make_uint4(pack2<T>(x0[0], x0[1]), pack2<T>(x0[2], x0[3]), pack2<T>(x0[4], x0[5]), pack2<T>(x0[6], x0[7]));
         const uint4 o1 = make_uint4(pack2<T>(x1[0], x1[1]), pack2<T>(x1[2], x1[3]), pack2<T>(x1[4], x1[5]), pack2<T>(x1[6], x1[7]));
-        uint16_t* dst = p.proc + ((size_t) vec * p.rows + row) * D;
-        *reinterpret_cast<uint4*>(dst + d0) = o0;
-        *reinterpret_cast<uint4*>(dst + d1) = o1;
+        if (vec < Hq || !p.kv_from_cache)
+        {
+            uint16_t* dst = p.proc + ((size_t) vec * p.rows + row) * D;
+            *reinterpret_cast<uint4*>(dst + d0) = o0;
+            *reinterpret_cast<uint4*>(dst + d1) = o1;
+        }
         if (bp && vec >= Hq)
         {
             const int kv = (vec - Hq) / Hkv, hk = (vec - Hq) % Hkv;
@@ -1141,6 +1146,22 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
         && (q.position_embedding_type == 0 || q.position_embedding_type == 1 || q.position_embedding_type == 3
             || q.position_embedding_type == 4 || q.position_embedding_type == 5
             || (q.position_embedding_type == 2 && q.rotary_embedding_dim == q.head_size));
+    // One copy of K / V instead of two: with a 16-bit cache that keeps every token at its own slot (no window, no sink
+    // tokens) the attention kernel can read the keys and values this call has just appended -- its chunked-context form
+    // with an empty past -- and the prepare pass then writes them to the cache only (a third less traffic in that
+    // pass; the values are the same T-rounded bits either way).  The chunked-context form of the attention kernel is
+    // the slower one per key (block pointers, less L2 locality), so this pays while the prepare pass is a large part of
+    // the call -- short prompts, small heads, few query heads per kv head (tools/lab_ctx_from_cache.py: B8 S512 D128
+    // 89.5 -> 78.9 us, B4 S2048 D64 163.7 -> 140.2; B4 S2048 D128 even; 64q / 8kv S4096 621 -> 669, left as it was)
+    const bool from_cache = !cached && fast && has_cache && a.kv_type == 0 && !windowed && q.sink_token_length == 0
+        && (q.head_size == 64 || q.head_size == 128) && (size_t) q.max_context_length * q.head_size <= 2048 * 64
+        && q.num_heads <= 2 * q.num_kv_heads && !lab_env("MI355Q_CTX_TWO_COPIES");
+    if (from_cache)
+    {
+        a.kv_from_cache = 1;
+        a.kv_lens = q.context_lengths; // kv length = context length: past 0
+    }
+    const bool attn_cached = cached || from_cache;
     if (fast && bf)
         hipLaunchKernelGGL(ctx_prepare_fast_kernel<bf16_t>, pgrid, dim3(256), 0, stream, a);
     else if (fast)
@@ -1170,11 +1191,11 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
 #define MQ_CTX_LAUNCH(TT, DD)                                                                                          \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (cached && bias == 2)                                                                                       \
+        if (attn_cached && bias == 2)                                                                                  \
             MQ_CTX_LAUNCH2(TT, DD, true, 2);                                                                           \
-        else if (cached && bias)                                                                                       \
+        else if (attn_cached && bias)                                                                                  \
             MQ_CTX_LAUNCH2(TT, DD, true, 1);                                                                           \
-        else if (cached)                                                                                               \
+        else if (attn_cached)                                                                                          \
             MQ_CTX_LAUNCH2(TT, DD, true, 0);                                                                           \
         else if (bias == 2)                                                                                            \
             MQ_CTX_LAUNCH2(TT, DD, false, 2);                                                                          \

@@ -1,0 +1,20 @@
+"""Lab: context attention with K / V read back from the cache (one copy) against the two-copy form
+(MI355Q_CTX_TWO_COPIES=1), LAB library, interleaved."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MI355Q_LIB", os.path.join(ROOT, "tensorrt-llm_amd", "lib", "libmi355q_lab.so"))
+import torch, bench
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+for kw in (dict(B=4), dict(B=1, S=4096), dict(B=8, S=512), dict(B=4, D=64, S=2048), dict(B=2, H=64, Hkv=8, S=4096)):
+    res = {"one": [], "two": []}
+    for rep in range(3):
+        for name in ("one", "two"):
+            if name == "two":
+                os.environ["MI355Q_CTX_TWO_COPIES"] = "1"
+            else:
+                os.environ.pop("MI355Q_CTX_TWO_COPIES", None)
+            r = bench.bench_context_attention(dev, 10, **kw)
+            res[name].append(round(r["ms_per_call"] * 1e3, 1))
+    print(kw, res, flush=True)
