@@ -506,10 +506,33 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
     // CACHED: the lane's K / V block bases of the tile staged NEXT, loaded one tile ahead so that their latency hides
     // behind a tile of compute (the values are only touched after the loop's own vmcnt(0))
     uint64_t kblk[CACHED ? DPW : 1], vblk[CACHED ? DPW : 1];
+    // Blocks of at least a tile (64 tokens; the linear buffer is one block): a 64-key tile lies inside ONE block, its rows
+    // are contiguous there like the workspace's, and the block base is wave-uniform -- one scalar load per tile and the
+    // same DMA addressing as the non-cached form, instead of a pointer load and 64-bit address arithmetic per lane and
+    // DMA (that difference was why this form ran ~10 % behind the other per key, tools/lab_ctx_from_cache.py)
+    const bool uni_blocks = CACHED && p.tpb_log2 >= 6;
+    uint64_t kblk_u = 0, vblk_u = 0;
     auto fetch_blocks = [&](int tile)
     {
         if constexpr (CACHED)
         {
+            if (uni_blocks)
+            {
+                const int blk = min(tile * CTX_KT, kv_len - 1) >> p.tpb_log2;
+                if (p.linear_base)
+                {
+                    kblk_u = (uint64_t) (p.linear_base + ((size_t) b * 2) * p.linear_plane_bytes);
+                    vblk_u = kblk_u + p.linear_plane_bytes;
+                    // (no return: the last tile of a plane whose length is not a multiple of 64 takes the per-lane,
+                    // clamped form below -- its rows past the plane are not this buffer's)
+                }
+                else
+                {
+                    kblk_u = (uint64_t) p.block_ptrs[((size_t) b * 2) * p.max_blocks + blk];
+                    vblk_u = (uint64_t) p.block_ptrs[((size_t) b * 2 + 1) * p.max_blocks + blk];
+                    return;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
             {
@@ -535,6 +558,21 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
         if constexpr (CACHED)
         {
             const int tmask = (1 << p.tpb_log2) - 1;
+            if (uni_blocks && (!p.linear_base || t0 + CTX_KT <= p.head_tokens))
+            {
+                // rows past the sequence are rows of the same (allocated) block: read as they are, masked later
+                const size_t in_blk = ((size_t) hk * p.head_tokens + (t0 & tmask)) * ROWB;
+                const uint8_t* kt = reinterpret_cast<const uint8_t*>(kblk_u) + in_blk;
+                const uint8_t* vt = reinterpret_cast<const uint8_t*>(vblk_u) + in_blk;
+#pragma unroll
+                for (int i = 0; i < DPW; ++i)
+                {
+                    const uint32_t kdst = lds_base + buf * STAGE_BYTES + (wave * DPW + i) * 1024;
+                    ctx_dma16(kt + krel[i], kdst);
+                    ctx_dma16(vt + vrel[i], kdst + TILE_BYTES);
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
             {
@@ -1149,13 +1187,13 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     // One copy of K / V instead of two: with a 16-bit cache that keeps every token at its own slot (no window, no sink
     // tokens) the attention kernel can read the keys and values this call has just appended -- its chunked-context form
     // with an empty past -- and the prepare pass then writes them to the cache only (a third less traffic in that
-    // pass; the values are the same T-rounded bits either way).  The chunked-context form of the attention kernel is
-    // the slower one per key (block pointers, less L2 locality), so this pays while the prepare pass is a large part of
-    // the call -- short prompts, small heads, few query heads per kv head (tools/lab_ctx_from_cache.py: B8 S512 D128
-    // 89.5 -> 78.9 us, B4 S2048 D64 163.7 -> 140.2; B4 S2048 D128 even; 64q / 8kv S4096 621 -> 669, left as it was)
+    // pass; the values are the same T-rounded bits either way).  tools/lab_ctx_from_cache.py, interleaved: B8 S512
+    // 89.6 -> 76.9 us, B4 S2048 D64 165.3 -> 142.8, B1 S4096 206.9 -> 190.8, B4 S2048 272.3 -> 267.5.  Not with many
+    // query heads per kv head: K / V are a small part of the pass there, and the scattered 16 KiB block pieces read
+    // a little slower than the workspace's contiguous megabyte per head (64q / 8kv S4096: 615 -> 640 us)
     const bool from_cache = !cached && fast && has_cache && a.kv_type == 0 && !windowed && q.sink_token_length == 0
-        && (q.head_size == 64 || q.head_size == 128) && (size_t) q.max_context_length * q.head_size <= 2048 * 64
-        && q.num_heads <= 2 * q.num_kv_heads && !lab_env("MI355Q_CTX_TWO_COPIES");
+        && (q.head_size == 64 || q.head_size == 128) && (q.num_heads <= 2 * q.num_kv_heads || lab_env("MI355Q_CTX_ONE_COPY"))
+        && !lab_env("MI355Q_CTX_TWO_COPIES");
     if (from_cache)
     {
         a.kv_from_cache = 1;

@@ -15,6 +15,7 @@ for kw in (dict(B=4), dict(B=1, S=4096), dict(B=8, S=512), dict(B=4, D=64, S=204
                 os.environ["MI355Q_CTX_TWO_COPIES"] = "1"
             else:
                 os.environ.pop("MI355Q_CTX_TWO_COPIES", None)
+                os.environ["MI355Q_CTX_ONE_COPY"] = "1"     # past the release gate
             r = bench.bench_context_attention(dev, 10, **kw)
             res[name].append(round(r["ms_per_call"] * 1e3, 1))
     print(kw, res, flush=True)
