@@ -138,15 +138,18 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
 // wave, far shorter than an HBM round trip, and with one tile in flight per workgroup the launch is latency-bound).  At
 // MT = 4 the ring's 64 KiB of LDS leave 2 workgroups per CU where the ping-pong has 5, and the ping-pong wins (grouped
 // MoE launch, 64 rows per expert: 167 against 192 us, tools/lab_moe_depth.py).
-// INTD (int4, the 32-row tiles of a weight stream -- the grouped MoE launch at decode): the integer domain of the
-// decode GEMV (gemv_tile_int4, woq_gemm.hip).  At MT = 2 a dequantised fragment feeds two MFMAs and the exact
-// dequantisation's 23 vector-ALU operations per 8 weights are the bound, next to HBM; here the nibbles go to the
-// MFMA as u = 0 .. 15 (7 operations per 8 weights) and scale / zero meet the accumulator once per group,
-// acc += s (P - 8 S1) + z S1 with S1 = sum a from one more MFMA against ones per (k-step, m-block).
+// INTD (int4 experts of the grouped MoE launch at decode: per-column scales, no zeros, <= 64-row tiles of a weight
+// stream): the integer domain of the decode GEMV (gemv_tile_int4, woq_gemm.hip) with the scale deferred to the
+// epilogue.  At these heights a dequantised fragment feeds 2 - 4 MFMAs and the exact dequantisation's 23 vector-ALU
+// operations per 8 weights are the bound, next to HBM; here the nibbles go to the MFMA as u = 0 .. 15 (7 operations per
+// 8 weights), P = sum a u and S1 = sum a accumulate over the workgroup's whole k range (S1 by one more MFMA against
+// ones per k-step, m-block j on wave j % NW, shared through LDS at the end), and out = s (P - 8 S1) once -- for a
+// one-hot activation row that is s q exactly.  No scale registers in the ring: 107 registers, 4 workgroups per CU (the
+// per-group form of the same arithmetic needed 160 and ran 3: the launch lives on bytes in flight).
 template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2, int NW = PF_WAVES, bool INTD = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
 {
-    static_assert(!INTD || WBITS == 4, "integer domain: int4 weights");
+    static_assert(!INTD || (WBITS == 4 && !ZERO && NSZ == 1), "integer domain with deferred scales: int4, per-column, no zeros");
     constexpr int PF_TN = NB * 16 * NW;
     constexpr int KTILE = Geo<WBITS>::KTILE;   // 128 (int4) / 64 (int8) rows of k per weight tile
     constexpr int KSTEPS = Geo<WBITS>::KSTEPS; // MFMA k-steps per tile
@@ -257,8 +260,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     struct WTile
     {
         uint4 w[NB];
-        uint32_t s[NB][NSZ], z[NB][NSZ]; // 16-bit values, zero-extended: column lane & 15 (A-operand row)
-        uint2 s4[NB][NSZ], z4[NB][NSZ];  // INTD instead: the lane's four output rows 4 (lane >> 4) .. + 3 (D layout)
+        uint32_t s[NB][NSZ], z[NB][NSZ]; // 16-bit values, zero-extended (not loaded with INTD: applied in the epilogue)
     };
     auto load_sz = [&](WTile& t, int kt)
     {
@@ -268,13 +270,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             for (int h = 0; h < NSZ; ++h)
             {
                 const int k = min(kt * KTILE + h * 64, a.k - 1);
-                if constexpr (INTD)
-                {
-                    const size_t si = (size_t) (k >> a.group_shift) * a.n + (size_t) (nb0 + b) * 16 + 4 * (lane >> 4);
-                    t.s4[b][h] = *reinterpret_cast<const uint2*>(a.scales + si);
-                    t.z4[b][h] = ZERO ? *reinterpret_cast<const uint2*>(a.zeros + si) : make_uint2(0u, 0u);
-                }
-                else
+                if constexpr (!INTD)
                 {
                     const size_t si = (size_t) (k >> a.group_shift) * a.n + col0 + b * 16;
                     t.s[b][h] = a.scales[si];
@@ -311,9 +307,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
             for (int h = 0; h < NSZ; ++h)
             {
-                if constexpr (INTD)
-                    asm volatile("" : "+v"(t.s4[b][h].x), "+v"(t.s4[b][h].y), "+v"(t.z4[b][h].x), "+v"(t.z4[b][h].y));
-                else
+                if constexpr (!INTD)
                     asm volatile("" : "+v"(t.s[b][h]), "+v"(t.z[b][h]));
             }
         }
@@ -347,68 +341,45 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         __syncthreads();
     }
 
-    auto compute_intd = [&](const WTile& t, int buf, int steps)
+    constexpr int S1N = INTD ? (MT + NW - 1) / NW : 1; // m-blocks whose S1 this wave accumulates: j = wave + NW i
+    f32x4_t s1all[S1N];
+#pragma unroll
+    for (int i = 0; i < S1N; ++i)
+        s1all[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto compute_deferred = [&](const WTile& t, int buf, int steps)
     {
-        constexpr int KG = KSTEPS / NSZ; // k-steps per (scale, zero) group
         const uint8_t* sa = frag_base + buf * BUF_BYTES;
         const uint4 ones = ones8<T>();
-        pf_static_for<NSZ>(
-            [&](auto hc)
+        pf_static_for<KSTEPS>(
+            [&](auto stc)
             {
-                constexpr int h = decltype(hc)::value;
-                if (h * KG >= steps) // the int4 half tile: its second group is past k
+                constexpr int st = decltype(stc)::value;
+                if (st >= steps)
                     return;
-                f32x4_t pacc[NB][MT], s1[MT];
-#pragma unroll
-                for (int j = 0; j < MT; ++j)
-                {
-                    s1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        pacc[b][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                }
-                pf_static_for<KG>(
-                    [&](auto gc)
-                    {
-                        constexpr int st = h * KG + decltype(gc)::value;
-                        uint4 wf[NB];
-#pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            wf[b] = unpack8_u4<T>(reinterpret_cast<const uint32_t*>(&t.w[b])[st]);
-                        const int coff = ((st * 4 + fk) ^ fsw) << 4;
-                        constexpr int AF = MT - 1 < 3 ? MT - 1 : 3, R = AF + 1;
-                        const uint32_t abase = (uint32_t) (uintptr_t) (lds_void_t*) sa + (uint32_t) coff;
-                        pf_u32x4_t av[R];
-                        pf_static_for<AF>(
-                            [&](auto jc) { pf_lds_read<decltype(jc)::value * 16 * RB>(av[decltype(jc)::value % R], abase); });
-                        pf_static_for<MT>(
-                            [&](auto jc)
-                            {
-                                constexpr int j = decltype(jc)::value;
-                                if constexpr (j + AF < MT)
-                                    pf_lds_read<(j + AF) * 16 * RB>(av[(j + AF) % R], abase);
-                                constexpr int issued = j + AF < MT ? j + 1 + AF : MT;
-                                pf_lds_wait<issued - (j + 1)>(av[j % R]);
-                                const uint4 af = __builtin_bit_cast(uint4, av[j % R]);
-#pragma unroll
-                                for (int b = 0; b < NB; ++b)
-                                    pacc[b][j] = mfma16<T>(wf[b], af, pacc[b][j]);
-                                s1[j] = mfma16<T>(ones, af, s1[j]);
-                            });
-                    });
+                uint4 wf[NB];
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                {
-                    const float sv[4] = {T16<T>::lo(t.s4[b][h].x), T16<T>::hi(t.s4[b][h].x), T16<T>::lo(t.s4[b][h].y),
-                        T16<T>::hi(t.s4[b][h].y)};
-                    const float zv[4] = {T16<T>::lo(t.z4[b][h].x), T16<T>::hi(t.z4[b][h].x), T16<T>::lo(t.z4[b][h].y),
-                        T16<T>::hi(t.z4[b][h].y)};
+                    wf[b] = unpack8_u4<T>(reinterpret_cast<const uint32_t*>(&t.w[b])[st]);
+                const int coff = ((st * 4 + fk) ^ fsw) << 4;
+                constexpr int AF = MT - 1 < 3 ? MT - 1 : 3, R = AF + 1;
+                const uint32_t abase = (uint32_t) (uintptr_t) (lds_void_t*) sa + (uint32_t) coff;
+                pf_u32x4_t av[R];
+                pf_static_for<AF>([&](auto jc) { pf_lds_read<decltype(jc)::value * 16 * RB>(av[decltype(jc)::value % R], abase); });
+                pf_static_for<MT>(
+                    [&](auto jc)
+                    {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j + AF < MT)
+                            pf_lds_read<(j + AF) * 16 * RB>(av[(j + AF) % R], abase);
+                        constexpr int issued = j + AF < MT ? j + 1 + AF : MT;
+                        pf_lds_wait<issued - (j + 1)>(av[j % R]);
+                        const uint4 af = __builtin_bit_cast(uint4, av[j % R]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < MT; ++j)
-                            acc[b][j][i] = fmaf(sv[i], fmaf(-8.f, s1[j][i], pacc[b][j][i]), fmaf(zv[i], s1[j][i], acc[b][j][i]));
-                }
+                        for (int b = 0; b < NB; ++b)
+                            acc[b][j] = mfma16<T>(wf[b], af, acc[b][j]);
+                        if (j % NW == wave) // wave-uniform
+                            s1all[j / NW] = mfma16<T>(ones, af, s1all[j / NW]);
+                    });
             });
     };
     auto compute_exact = [&](const WTile& t, int buf, int steps)
@@ -475,7 +446,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     auto compute = [&](const WTile& t, int buf, int steps)
     {
         if constexpr (INTD)
-            compute_intd(t, buf, steps);
+            compute_deferred(t, buf, steps);
         else
             compute_exact(t, buf, steps);
     };
@@ -516,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         // weight and scale / zero loads.  vmcnt retires in order, so "tile kt has landed" = at most (tiles issued
         // after it) x L operations outstanding.  hipcc cannot see the DMAs and adds its own, somewhat stricter wait
         // in front of landed(); the explicit one is what covers the DMAs.
-        constexpr int L = DMA_PER_WAVE + NB * (1 + NSZ * (ZERO ? 2 : 1));
+        constexpr int L = DMA_PER_WAVE + NB * (1 + (INTD ? 0 : NSZ * (ZERO ? 2 : 1)));
         static_assert((DEPTH - 2) * L < 64, "vmcnt immediate");
         auto issue = [&](auto slot, int kt)
         {
@@ -569,6 +540,34 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 
     // epilogue.  D[row = n][col = m]: lane holds n = 4*(l>>4) + {0..3}, m = l & 15.
     const int em = lane & 15, en = (lane >> 4) * 4;
+    if constexpr (INTD)
+    {
+        // the deferred scales: acc holds P = sum a u over this workgroup's k range, the waves' s1all the matching
+        // sum a (every D row of an MFMA against ones is S1[m]: lanes 0 .. 15 hold it).  Shared through LDS -- the
+        // k loop's buffers are free after its last barrier --, then out (or this split's slab) = s (P - 8 S1).
+        float* s1x = reinterpret_cast<float*>(lds);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < S1N; ++i)
+            if (wave + NW * i < MT && lane < 16)
+                s1x[(wave + NW * i) * 16 + lane] = s1all[i][0];
+        __syncthreads();
+        float s1[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            s1[j] = s1x[j * 16 + em];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+        {
+            const uint2 sv2 = *reinterpret_cast<const uint2*>(a.scales + (size_t) (nb0 + b) * 16 + en);
+            const float sv[4] = {T16<T>::lo(sv2.x), T16<T>::hi(sv2.x), T16<T>::lo(sv2.y), T16<T>::hi(sv2.y)};
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[b][j][i] = sv[i] * fmaf(-8.f, s1[j], acc[b][j][i]);
+        }
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b)
     {
@@ -1313,6 +1312,8 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
             ks = (int) std::min<int64_t>(std::min<int64_t>(8, ktiles / 8), (2048 + wgs - 1) / wgs);
             const size_t per = (size_t) p.total_rows * p.gemm_n * sizeof(float);
             ks = (int) std::min<size_t>(ks, p.splitk_workspace_bytes / per);
+            if (const char* e = lab_env("MI355Q_MOE_KS")) // lab: force the split
+                ks = std::max(1, std::min(atoi(e), (int) (p.splitk_workspace_bytes / per)));
         }
         if (ks > 1)
         {
@@ -1346,8 +1347,8 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (MTV <= 2 && WB == 4 && !lab_env("MI355Q_MOE_EXACT"))                                                       \
-            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, (MTV <= 2 && WB == 4)>), \
+        if (MTV <= 4 && WB == 4 && !lab_env("MI355Q_MOE_EXACT"))                                                       \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, (MTV <= 4 && WB == 4)>), \
                 dim3(tiles_m * tiles_n, a.ksplit), dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);               \
         else if (MTV <= 2 && !lab_env("MI355Q_PF_DEPTH2"))                                                             \
             hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \

@@ -78,5 +78,33 @@ def test_moe_gemm_prefill_sized_experts_big_tile(cuda, dtype_str):
     _case(cuda, [257, 511, 300], 8192, 192, dtype_str, L.WEIGHT_INT4, "silu", True)
 
 
+@pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
+@pytest.mark.parametrize("rows", [16, 48])
+def test_moe_gemm_identity_rows_recover_dequantised_weights(cuda, dtype_str, rows):
+    # the reference's identity-activation gate (test_weight_only_quant_matmul.py:44-53) through the grouped launch's
+    # integer-domain tiles (int4 experts, <= 64 rows per expert): one-hot rows must return round16(q * scale) bit for bit
+    torch.manual_seed(3)
+    dt = DT[dtype_str]
+    E, k, n = 3, 256, 384
+    q_all, proc_all, sc_all = [], [], []
+    for e in range(E):
+        weight = torch.rand(k, n, dtype=dt) * 2 - 1.0
+        unproc, proc, scales = F._symmetric_quantize_last_axis_of_batched_matrix(weight, torch.quint4x2)
+        q_all.append(oracle.unpack_int4_packed_tensor_to_int8(unproc.numpy()))
+        proc_all.append(proc)
+        sc_all.append(scales.reshape(-1))
+    proc = torch.stack(proc_all).contiguous()
+    scales = torch.stack(sc_all).contiguous()
+    picks = [torch.randperm(k)[:rows] for _ in range(E)]
+    a = torch.cat([torch.eye(k, dtype=dt)[pk] for pk in picks], 0)
+    cum = torch.tensor([rows * (e + 1) for e in range(E)], dtype=torch.int64)
+    out = F.moe_gemm_bias_act(a.to(cuda), proc.to(cuda), scales.to(cuda), None, cum.to(cuda), L.WEIGHT_INT4, ACT["identity"])
+    torch.cuda.synchronize()
+    for e in range(E):
+        w = (torch.from_numpy(q_all[e]).float() * scales[e].float()[None, :]).to(dt)       # round16(q * s)
+        got = out[e * rows:(e + 1) * rows].cpu()
+        assert torch.equal(got.view(torch.int16), w[picks[e]].view(torch.int16)), f"expert {e}"
+
+
 def test_moe_gemm_no_rows(cuda):
     _case(cuda, [0, 0, 0], 128, 128, "float16", L.WEIGHT_INT8, "identity", False)
