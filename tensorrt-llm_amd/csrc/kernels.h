@@ -60,7 +60,9 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream);
 // the skinny form (16 < m <= 64, one burst per workgroup, split-K closed inside the launch); false = does not apply
 size_t woq_skinny_workspace_size(int m, int n, int k, int weight_type);
 bool weight_only_skinny_gemm(const WoqArgsHost& h, void* workspace, size_t workspace_bytes, hipStream_t stream);
-void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream);
+// returns the split-K count used; reduce = false leaves the fp32 slabs in p.splitk_workspace ([splits][total_rows][gemm_n])
+// for the caller to sum (run_moe's finalize step does), instead of launching the reduce kernel into p.C
+int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce = true);
 size_t moe_workspace_size(const mi355q_moe_params& p);
 void run_moe(const mi355q_moe_params& p, hipStream_t stream);
 void apply_per_channel_scale(

@@ -46,6 +46,8 @@ struct MoeArgs
     uint16_t* fc1;        // [n, inter]
     uint16_t* glu;        // [n, 2 inter] (gated activations)
     uint16_t* fc2;        // [n, hidden]
+    const float* fc2_slabs; // split-K w2 GEMM: fp32 [fc2_splits][n][hidden] instead of fc2, summed by the finalize step
+    int fc2_splits;
     int num_rows, hidden, inter, num_experts, k, n;
     int start_expert, experts_per_node, buckets, nblocks;
     int act_fn, scale_mode, add_bias; // scale_mode: 0 none, 1 routing scale, 2 renormalised
@@ -353,8 +355,28 @@ __global__ __launch_bounds__(256) void moe_finalize_kernel(MoeArgs a)
         rescale += sc;
         if (dest >= num_valid)
             continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(a.fc2 + (size_t) dest * a.hidden + 8 * c8);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t w[4];
+        if (a.fc2_splits > 1)
+        {
+            // the w2 GEMM's split-K slabs, summed in split order and rounded to T exactly as its reduce kernel would
+            // have (woq_splitk_reduce_kernel): one launch and one pass over fc2 less
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* sl = a.fc2_slabs + (size_t) dest * a.hidden + 8 * c8;
+            for (int s = 0; s < a.fc2_splits; ++s, sl += (size_t) a.n * a.hidden)
+            {
+                const float4 lo = *reinterpret_cast<const float4*>(sl), hi = *reinterpret_cast<const float4*>(sl + 4);
+                f[0] += lo.x, f[1] += lo.y, f[2] += lo.z, f[3] += lo.w;
+                f[4] += hi.x, f[5] += hi.y, f[6] += hi.z, f[7] += hi.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = pack2<T>(f[2 * q], f[2 * q + 1]);
+        }
+        else
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.fc2 + (size_t) dest * a.hidden + 8 * c8);
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+        }
         if (a.add_bias)
         {
             const int e = a.experts[(size_t) row * a.k + j];
@@ -542,7 +564,8 @@ void run_moe(const mi355q_moe_params& p, hipStream_t stream)
     g.activation_type = 5;
     g.splitk_workspace = l.slab_bytes ? ws + l.slabs : nullptr;
     g.splitk_workspace_bytes = l.slab_bytes;
-    moe_weight_only_gemm(g, stream);
+    a.fc2_splits = moe_weight_only_gemm(g, stream, false); // split-K: the slabs go to the finalize step, no reduce launch
+    a.fc2_slabs = reinterpret_cast<const float*>(g.splitk_workspace);
     if (bf)
         hipLaunchKernelGGL(moe_finalize_kernel<bf16_t>, dim3(p.num_rows, (p.hidden_size / 8 + 255) / 256), dim3(256), 0, stream, a);
     else

@@ -1260,10 +1260,10 @@ int moe_pick_tile(int64_t total_rows, int experts, bool allow256)
 // scans the cumulative row counts (device memory, <= 64 scalar loads), finds its expert and is from then on a tile of
 // that expert's GEMM.  The grid is sized for the worst case sum_e ceil(rows_e / TM) <= ceil(total / TM) + experts;
 // surplus workgroups leave at once.
-void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
+int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce)
 {
     if (p.total_rows <= 0)
-        return;
+        return 1;
     MQ_CHECK(p.A && p.B && p.weight_scales && p.C && p.total_rows_before_expert, "null tensor");
     MQ_CHECK(p.act_type == MI355Q_HALF || p.act_type == MI355Q_BF16, "Unsupported data type %d", p.act_type);
     MQ_CHECK(p.weight_type == MI355Q_WEIGHT_INT4 || p.weight_type == MI355Q_WEIGHT_INT8, "weight_type %d", p.weight_type);
@@ -1340,7 +1340,7 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
             hipLaunchKernelGGL((woq_prefill_kernel<f16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream, a,
                 tm16, tn16);
         MQ_HIP(hipGetLastError());
-        return;
+        return 1;
     }
     const int tiles_m = (int) ((p.total_rows + mt * 16 - 1) / (mt * 16)) + p.num_experts;
     const int tiles_n = a.n / 128;
@@ -1373,9 +1373,10 @@ void moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream)
     else MQ_MOE_MT(f16_t, 8);
 #undef MQ_MOE_MT
 #undef MQ_MOE
-    if (a.ksplit > 1) // rows past the last expert's hold whatever the workspace held: nobody reads them
+    if (a.ksplit > 1 && reduce) // rows past the last expert's hold whatever the workspace held: nobody reads them
         woq_splitk_reduce(a.slabs, nullptr, nullptr, p.C, (int) p.total_rows, (int) p.gemm_n, a.ksplit, bf, stream);
     MQ_HIP(hipGetLastError());
+    return a.ksplit;
 }
 
 } // namespace mi355q
