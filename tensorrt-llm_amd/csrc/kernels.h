@@ -62,7 +62,10 @@ size_t woq_skinny_workspace_size(int m, int n, int k, int weight_type);
 bool weight_only_skinny_gemm(const WoqArgsHost& h, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // returns the split-K count used; reduce = false leaves the fp32 slabs in p.splitk_workspace ([splits][total_rows][gemm_n])
 // for the caller to sum (run_moe's finalize step does), instead of launching the reduce kernel into p.C
-int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce = true);
+// row_map: p.A holds the UN-permuted rows and row r of the expert order is row row_map[r] % row_mod of it (the layer's
+// dest_to_src map: no gather pass); null = p.A is in expert order
+int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce = true,
+    const int32_t* row_map = nullptr, int row_mod = 1);
 size_t moe_workspace_size(const mi355q_moe_params& p);
 void run_moe(const mi355q_moe_params& p, hipStream_t stream);
 void apply_per_channel_scale(

@@ -9,7 +9,8 @@
 //                            all three when the pairs fit one chunk (decode), else three launches.  Also the inclusive
 //                            per-expert row counts (computeTotalRowsBeforeExpertKernel, :566-578) and both
 //                            permutation maps
-//   3. moe_expand_kernel     the gather of the token rows into expert order (expandInputRowsKernel, :593-623)
+//   3. (the gather of the token rows into expert order, expandInputRowsKernel :593-623, is not a pass of its own: the
+//      grouped GEMM 1 reads its activation rows through the dest_to_src map while it stages them)
 //   4. grouped GEMM 1 (+ bias + activation in its epilogue; identity for a gated activation)
 //   5. moe_gated_act_kernel  fc1 * act(gate) (doGatedActivationKernel, :795-817)
 //   6. grouped GEMM 2
@@ -42,7 +43,6 @@ struct MoeArgs
     int32_t* dest_to_src; // [n]
     int32_t* blk_counts;  // [buckets, nblocks] histogram, then exclusive offsets
     int64_t* total_rows;  // [experts_per_node] inclusive
-    uint16_t* permuted;   // [n, hidden]
     uint16_t* fc1;        // [n, inter]
     uint16_t* glu;        // [n, 2 inter] (gated activations)
     uint16_t* fc2;        // [n, hidden]
@@ -288,20 +288,6 @@ __global__ __launch_bounds__(256) void moe_sort_small_kernel(MoeArgs a)
     moe_place(a, 0, key, wave_tot, [&](int e) { return hist[e]; });
 }
 
-// ---- 3. gather.  grid n, block 256: destination row d <- input row (dest_to_src[d] % num_rows); rows of the
-// sentinel bucket (past the last expert's end) are not copied
-__global__ __launch_bounds__(256) void moe_expand_kernel(MoeArgs a)
-{
-    const int dest = blockIdx.x;
-    if (dest >= a.total_rows[a.experts_per_node - 1])
-        return;
-    const int row = a.dest_to_src[dest] % a.num_rows;
-    const uint4* src = reinterpret_cast<const uint4*>(a.input + (size_t) row * a.hidden);
-    uint4* dst = reinterpret_cast<uint4*>(a.permuted + (size_t) dest * a.hidden);
-    for (int i = threadIdx.x; i < a.hidden / 8; i += 256)
-        dst[i] = src[i];
-}
-
 __device__ __forceinline__ float moe_act(float x, int fn) // Swiglu -> SiLU, Geglu -> GELU_taylor (:828-831)
 {
     return fn == 3 ? x / (1.f + __expf(-x)) : 0.5f * x * (1.f + tanhf(0.7978845608028654f * x * (1.f + 0.044715f * x * x)));
@@ -411,7 +397,7 @@ size_t align256(size_t x)
 
 struct MoeLayout
 {
-    size_t scales, experts, src_to_dest, dest_to_src, blk_counts, total_rows, permuted, fc1, glu, fc2, slabs, slab_bytes, total;
+    size_t scales, experts, src_to_dest, dest_to_src, blk_counts, total_rows, fc1, glu, fc2, slabs, slab_bytes, total;
     int n, nblocks, buckets, experts_per_node;
     bool gated;
 };
@@ -445,7 +431,6 @@ MoeLayout moe_layout(const mi355q_moe_params& p)
     l.dest_to_src = take(n * 4);
     l.blk_counts = take((size_t) l.buckets * l.nblocks * 4);
     l.total_rows = take((size_t) l.experts_per_node * 8);
-    l.permuted = take(n * p.hidden_size * 2);
     l.fc1 = take(n * p.inter_size * 2);
     l.glu = take(l.gated ? n * p.inter_size * 4 : 0);
     l.fc2 = take(n * p.hidden_size * 2);
@@ -494,7 +479,6 @@ void run_moe(const mi355q_moe_params& p, hipStream_t stream)
     a.dest_to_src = reinterpret_cast<int32_t*>(ws + l.dest_to_src);
     a.blk_counts = reinterpret_cast<int32_t*>(ws + l.blk_counts);
     a.total_rows = reinterpret_cast<int64_t*>(ws + l.total_rows);
-    a.permuted = reinterpret_cast<uint16_t*>(ws + l.permuted);
     a.fc1 = reinterpret_cast<uint16_t*>(ws + l.fc1);
     a.glu = reinterpret_cast<uint16_t*>(ws + l.glu);
     a.fc2 = reinterpret_cast<uint16_t*>(ws + l.fc2);
@@ -529,11 +513,11 @@ void run_moe(const mi355q_moe_params& p, hipStream_t stream)
         hipLaunchKernelGGL(moe_sort_scan_kernel, dim3(1), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(moe_sort_scatter_kernel, dim3(l.nblocks), dim3(256), 0, stream, a);
     }
-    hipLaunchKernelGGL(moe_expand_kernel, dim3(l.n), dim3(256), 0, stream, a);
     MQ_HIP(hipGetLastError());
 
+    // (no expandInputRows pass: the w1 GEMM gathers its activation rows through dest_to_src while it stages them)
     mi355q_moe_gemm_params g{};
-    g.A = a.permuted;
+    g.A = a.input;
     g.B = p.fc1_expert_weights;
     g.weight_scales = p.fc1_scales;
     g.biases = p.fc1_expert_biases;
@@ -546,7 +530,7 @@ void run_moe(const mi355q_moe_params& p, hipStream_t stream)
     g.activation_type = l.gated ? 5 : p.activation_type;
     g.weight_type = p.weight_type;
     g.act_type = p.act_type;
-    moe_weight_only_gemm(g, stream);
+    moe_weight_only_gemm(g, stream, true, a.dest_to_src, p.num_rows);
     if (l.gated)
     {
         if (bf)

@@ -38,6 +38,10 @@ struct WoqArgs
     int moe_experts;
     size_t moe_wbytes;       // bytes of one expert's weight matrix
     int act_fn;              // epilogue activation (ActivationType of moe_gemm_kernels.h: 0 gelu, 1 relu, 2 silu, 5 identity)
+    // grouped form, rows gathered on the fly (run_moe: no expandInputRows pass): row r of the expert-sorted order is row
+    // moe_row_map[r] % moe_row_mod of `act`; null = `act` is already in expert order
+    const int32_t* moe_row_map;
+    int moe_row_mod;
 };
 
 // moeGemmBiasAct's epilogues (cutlass_extensions/epilogue_helpers.h: LinearCombination{Relu, Silu, Generic<GELU_taylor>})

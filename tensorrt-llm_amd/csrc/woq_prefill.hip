@@ -175,6 +175,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     }
     const int tn = bid / tiles_m;
     int tm = bid % tiles_m;
+    int moe_row0 = 0; // grouped form: the expert's first row in the expert-sorted order
     if (a.moe_rows)
     {
         // grouped form: m-tile index over all experts -> (expert, its m-tile); then this workgroup is an ordinary tile
@@ -195,7 +196,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             return;
         tm -= tiles_before;
         a.m = rows;
-        a.act += row0 * a.k;
+        moe_row0 = (int) row0;
+        if (!a.moe_row_map)
+            a.act += row0 * a.k;
         a.out += row0 * a.n;
         a.slabs += row0 * a.n;
         a.qweight += (size_t) e * a.moe_wbytes;
@@ -217,7 +220,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         const int d = wave * DMA_PER_WAVE + i;
         const int row = d * ROWS_PER_DMA + drow;
         // rows past m re-read the last row; never stored
-        aoff[i] = (uint32_t) min(m0 + row, a.m - 1) * (uint32_t) a.k * 2u + (dchunk ^ sw(row)) * 16;
+        uint32_t src_row = (uint32_t) min(m0 + row, a.m - 1);
+        if (a.moe_row_map) // gathered on the fly: the token row behind this expert-order row
+            src_row = (uint32_t) (a.moe_row_map[moe_row0 + (int) src_row] % a.moe_row_mod);
+        aoff[i] = src_row * (uint32_t) a.k * 2u + (dchunk ^ sw(row)) * 16;
     }
     // k range of this workgroup (split-K over grid.y); the int4 half tile belongs to the last split
     const bool half_tile = WBITS == 4 && (a.k & 127);
@@ -1260,7 +1266,7 @@ int moe_pick_tile(int64_t total_rows, int experts, bool allow256)
 // scans the cumulative row counts (device memory, <= 64 scalar loads), finds its expert and is from then on a tile of
 // that expert's GEMM.  The grid is sized for the worst case sum_e ceil(rows_e / TM) <= ceil(total / TM) + experts;
 // surplus workgroups leave at once.
-int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce)
+int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce, const int32_t* row_map, int row_mod)
 {
     if (p.total_rows <= 0)
         return 1;
@@ -1323,6 +1329,8 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
         }
     }
     a.moe_rows = p.total_rows_before_expert;
+    a.moe_row_map = row_map;
+    a.moe_row_mod = row_mod;
     a.moe_experts = p.num_experts;
     a.moe_wbytes = (size_t) p.gemm_n * p.gemm_k * (i4 ? 1 : 2) / 2;
     const bool bf = p.act_type == MI355Q_BF16;
