@@ -302,7 +302,8 @@ def bench_moe_layer(dev, steps, tokens=64, top_k=2, experts=8, hidden=4096, inte
     rows = tokens * top_k
     flops = 2.0 * rows * hidden * 2 * inter + 2.0 * rows * inter * hidden
     wbytes = experts * (hidden * inter + inter * hidden // 2) + experts * (2 * inter + hidden) * 2
-    abytes = tokens * hidden * 2 * 2 + rows * hidden * 2 * 3 + rows * 2 * inter * 2 * 2 + rows * inter * 2 * 2   # (gather fused into the w1 GEMM: its rows are read once, not written + read)
+    # (gather and SwiGLU fused into the w1 GEMM: its rows are read once, the [rows, 2 inter] buffer does not exist)
+    abytes = tokens * hidden * 2 * 2 + rows * hidden * 2 * 3 + rows * inter * 2 * 2
     return {"tokens": tokens, "top_k": top_k, "experts": experts, "hidden": hidden, "inter": inter,
             "weights": "int4 per-column", "activation": "swiglu", "us_per_call": t * 1e6, "TFLOPS": flops / t / 1e12,
             "GBps": (wbytes + abytes) / t / 1e9, "frac_of_8TBps": (wbytes + abytes) / t / 1e9 / HBM_PEAK_GBS,

@@ -64,8 +64,10 @@ bool weight_only_skinny_gemm(const WoqArgsHost& h, void* workspace, size_t works
 // for the caller to sum (run_moe's finalize step does), instead of launching the reduce kernel into p.C
 // row_map: p.A holds the UN-permuted rows and row r of the expert order is row row_map[r] % row_mod of it (the layer's
 // dest_to_src map: no gather pass); null = p.A is in expert order
+// glu_fn >= 0: gemm_n = 2 inter columns [linear | gate]; p.C receives [total_rows, inter] = linear * act(gate) with the
+// reference's roundings (doGatedActivationKernel), act = woq_activation code glu_fn (2 SiLU, 0 GELU); needs inter % 256 == 0
 int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce = true,
-    const int32_t* row_map = nullptr, int row_mod = 1);
+    const int32_t* row_map = nullptr, int row_mod = 1, int glu_fn = -1);
 size_t moe_workspace_size(const mi355q_moe_params& p);
 void run_moe(const mi355q_moe_params& p, hipStream_t stream);
 void apply_per_channel_scale(

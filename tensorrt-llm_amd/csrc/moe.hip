@@ -521,7 +521,10 @@ void run_moe(const mi355q_moe_params& p, hipStream_t stream)
     g.B = p.fc1_expert_weights;
     g.weight_scales = p.fc1_scales;
     g.biases = p.fc1_expert_biases;
-    g.C = l.gated ? a.glu : a.fc1;
+    // gated activations: fused into the w1 GEMM's epilogue when the tiles divide the halves (inter % 256: every tile
+    // form), else the [n, 2 inter] buffer and the gated-activation pass
+    const bool fuse_glu = l.gated && p.inter_size % 256 == 0;
+    g.C = (l.gated && !fuse_glu) ? a.glu : a.fc1;
     g.total_rows_before_expert = a.total_rows;
     g.total_rows = l.n;
     g.gemm_n = l.gated ? 2 * (int64_t) p.inter_size : p.inter_size;
@@ -530,8 +533,8 @@ void run_moe(const mi355q_moe_params& p, hipStream_t stream)
     g.activation_type = l.gated ? 5 : p.activation_type;
     g.weight_type = p.weight_type;
     g.act_type = p.act_type;
-    moe_weight_only_gemm(g, stream, true, a.dest_to_src, p.num_rows);
-    if (l.gated)
+    moe_weight_only_gemm(g, stream, true, a.dest_to_src, p.num_rows, fuse_glu ? (p.activation_type == 3 ? 2 : 0) : -1);
+    if (l.gated && !fuse_glu)
     {
         if (bf)
             hipLaunchKernelGGL(moe_gated_act_kernel<bf16_t>, dim3(l.n, (p.inter_size / 8 + 255) / 256), dim3(256), 0, stream, a);

@@ -42,6 +42,11 @@ struct WoqArgs
     // moe_row_map[r] % moe_row_mod of `act`; null = `act` is already in expert order
     const int32_t* moe_row_map;
     int moe_row_mod;
+    // gated activation fused into the epilogue (run_moe's w1 GEMM; doGatedActivationKernel, moe_kernels.cu:795-817): the
+    // n columns are [linear | gate] halves of glu_inter columns each; a wave takes matching n-blocks of both halves and
+    // stores T(T(linear) * T(act(T(gate)))) to out[m][glu_inter] -- no [m][2 inter] buffer, no second pass.  0 = off;
+    // glu_fn: woq_activation's code of the gate's activation (2 SiLU for Swiglu, 0 GELU for Geglu)
+    int glu_inter, glu_fn;
 };
 
 // moeGemmBiasAct's epilogues (cutlass_extensions/epilogue_helpers.h: LinearCombination{Relu, Silu, Generic<GELU_taylor>})

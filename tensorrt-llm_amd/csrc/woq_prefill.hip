@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         moe_row0 = (int) row0;
         if (!a.moe_row_map)
             a.act += row0 * a.k;
-        a.out += row0 * a.n;
+        a.out += row0 * (a.glu_inter ? a.glu_inter : a.n);
         a.slabs += row0 * a.n;
         a.qweight += (size_t) e * a.moe_wbytes;
         a.scales += (size_t) e * a.n;
@@ -260,9 +260,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 
     // ---- weights: this wave's two n-blocks, one k-tile per 16-byte load, one tile ahead
     const size_t run_bytes = (size_t) a.k * 16 * WBITS / 8;
-    const int nb0 = (n0 >> 4) + wave * NB;
-    const uint8_t* run0 = a.qweight + (size_t) nb0 * run_bytes;
-    const int col0 = nb0 * 16 + (lane & 15);
+    // the wave's n-blocks: NB adjacent ones, or -- gated epilogue -- NB / 2 of the linear half and the matching NB / 2
+    // of the gate half (the workgroup then covers PF_TN / 2 output columns)
+    int nbi[NB];
+    {
+        const int nb0 = (n0 >> 4) + wave * NB, lin0 = (n0 >> 5) + wave * (NB / 2);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            nbi[b] = !a.glu_inter ? nb0 + b : (b < NB / 2 ? lin0 + b : (a.glu_inter >> 4) + lin0 + (b - NB / 2));
+    }
     struct WTile
     {
         uint4 w[NB];
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
                 const int k = min(kt * KTILE + h * 64, a.k - 1);
                 if constexpr (!INTD)
                 {
-                    const size_t si = (size_t) (k >> a.group_shift) * a.n + col0 + b * 16;
+                    const size_t si = (size_t) (k >> a.group_shift) * a.n + nbi[b] * 16 + (lane & 15);
                     t.s[b][h] = a.scales[si];
                     t.z[b][h] = ZERO ? a.zeros[si] : (uint16_t) 0;
                 }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            t.w[b] = *reinterpret_cast<const uint4*>(run0 + (size_t) b * run_bytes + (size_t) kt * 1024 + lane * 16);
+            t.w[b] = *reinterpret_cast<const uint4*>(a.qweight + (size_t) nbi[b] * run_bytes + (size_t) kt * 1024 + lane * 16);
         load_sz(t, kt);
     };
     auto load_w_half = [&](WTile& t, int kt) // the 512-byte trailing half tile of int4 with k % 128 == 64: 8 bytes per lane
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
         for (int b = 0; b < NB; ++b)
         {
-            const uint2 hw = *reinterpret_cast<const uint2*>(run0 + (size_t) b * run_bytes + (size_t) kt * 1024 + lane * 8);
+            const uint2 hw = *reinterpret_cast<const uint2*>(a.qweight + (size_t) nbi[b] * run_bytes + (size_t) kt * 1024 + lane * 8);
             t.w[b] = make_uint4(hw.x, hw.y, 0, 0);
         }
         load_sz(t, kt);
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
         for (int b = 0; b < NB; ++b)
         {
-            const uint2 sv2 = *reinterpret_cast<const uint2*>(a.scales + (size_t) (nb0 + b) * 16 + en);
+            const uint2 sv2 = *reinterpret_cast<const uint2*>(a.scales + (size_t) nbi[b] * 16 + en);
             const float sv[4] = {T16<T>::lo(sv2.x), T16<T>::hi(sv2.x), T16<T>::lo(sv2.y), T16<T>::hi(sv2.y)};
 #pragma unroll
             for (int j = 0; j < MT; ++j)
@@ -574,12 +580,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
                     acc[b][j][i] = sv[i] * fmaf(-8.f, s1[j], acc[b][j][i]);
         }
     }
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
+    const float alpha = (a.alpha && a.ksplit == 1) ? a.alpha[0] : 1.f; // out = alpha * acc + bias
+    auto bias4 = [&](int n, float (&bias)[4])
     {
-        const int n = (nb0 + b) * 16 + en;
-        float bias[4] = {0.f, 0.f, 0.f, 0.f};
-        const float alpha = (a.alpha && a.ksplit == 1) ? a.alpha[0] : 1.f; // out = alpha * acc + bias
+        bias[0] = bias[1] = bias[2] = bias[3] = 0.f;
         if (a.bias && a.ksplit == 1)
         {
             const uint2 bv = *reinterpret_cast<const uint2*>(a.bias + n);
@@ -588,6 +592,43 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             bias[2] = T16<T>::lo(bv.y);
             bias[3] = T16<T>::hi(bv.y);
         }
+    };
+    if (a.glu_inter) // wave-uniform; the host only asks for it without split-K
+    {
+        // the reference's two steps in one: the GEMM's T-rounded outputs (bias added, identity activation), then
+        // out = T(linear * T(act(gate))) -- the values and roundings of moe_gated_act_kernel
+#pragma unroll
+        for (int b = 0; b < NB / 2; ++b)
+        {
+            const int n = nbi[b] * 16 + en, ng = nbi[b + NB / 2] * 16 + en;
+            float bl[4], bg[4];
+            bias4(n, bl);
+            bias4(ng, bg);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+            {
+                const int m = m0 + j * 16 + em;
+                if (m >= a.m)
+                    continue;
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    const float lin = T16<T>::to_float(T16<T>::from_float(acc[b][j][i] * alpha + bl[i]));
+                    const float gate = T16<T>::to_float(T16<T>::from_float(acc[b + NB / 2][j][i] * alpha + bg[i]));
+                    o[i] = lin * T16<T>::to_float(T16<T>::from_float(woq_activation(gate, a.glu_fn)));
+                }
+                *reinterpret_cast<uint2*>(a.out + (size_t) m * a.glu_inter + n) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+    {
+        const int n = nbi[b] * 16 + en;
+        float bias[4];
+        bias4(n, bias);
 #pragma unroll
         for (int j = 0; j < MT; ++j)
         {
@@ -1266,7 +1307,8 @@ int moe_pick_tile(int64_t total_rows, int experts, bool allow256)
 // scans the cumulative row counts (device memory, <= 64 scalar loads), finds its expert and is from then on a tile of
 // that expert's GEMM.  The grid is sized for the worst case sum_e ceil(rows_e / TM) <= ceil(total / TM) + experts;
 // surplus workgroups leave at once.
-int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce, const int32_t* row_map, int row_mod)
+int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bool reduce, const int32_t* row_map, int row_mod,
+    int glu_fn)
 {
     if (p.total_rows <= 0)
         return 1;
@@ -1331,6 +1373,13 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
     a.moe_rows = p.total_rows_before_expert;
     a.moe_row_map = row_map;
     a.moe_row_mod = row_mod;
+    if (glu_fn >= 0)
+    {
+        MQ_CHECK(a.ksplit == 1 && p.activation_type == 5 && p.gemm_n % 512 == 0,
+            "internal: fused gated activation needs an unsplit identity GEMM over 2 x (a multiple of 256) columns");
+        a.glu_inter = a.n / 2;
+        a.glu_fn = glu_fn;
+    }
     a.moe_experts = p.num_experts;
     a.moe_wbytes = (size_t) p.gemm_n * p.gemm_k * (i4 ? 1 : 2) / 2;
     const bool bf = p.act_type == MI355Q_BF16;
