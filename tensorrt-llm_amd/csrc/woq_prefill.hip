@@ -1357,7 +1357,9 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
         int ks = 1;
         if (p.splitk_workspace && !p.biases && p.activation_type == 5 && wgs < 768 && ktiles >= 16)
         {
-            ks = (int) std::min<int64_t>(std::min<int64_t>(8, ktiles / 8), (2048 + wgs - 1) / wgs);
+            // (one resident round of workgroups, 4 per CU: with the integer-domain tiles 4 splits beat 8 at the Mixtral
+            // decode shape, 51 vs 55 us, tools/lab_moe_ks.sh -- and the finalize step reads half the slabs)
+            ks = (int) std::min<int64_t>(std::min<int64_t>(8, ktiles / 8), (1024 + wgs - 1) / wgs);
             const size_t per = (size_t) p.total_rows * p.gemm_n * sizeof(float);
             ks = (int) std::min<size_t>(ks, p.splitk_workspace_bytes / per);
             if (const char* e = lab_env("MI355Q_MOE_KS")) // lab: force the split
