@@ -1392,6 +1392,8 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
     {
         mt = 16;
         const int tm16 = (int) ((p.total_rows + 255) / 256) + p.num_experts, tn16 = a.n / 256;
+        // (the exact dequantisation here: this tile is MFMA-bound, and the integer-domain form's extra MFMAs against ones
+        // cost it 7 % -- 4096 tokens, fc1 1.86 vs 2.00 ms, tools/lab_moe_intd.py)
         if (bf)
             hipLaunchKernelGGL((woq_prefill_kernel<bf16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream, a,
                 tm16, tn16);
@@ -1406,8 +1408,8 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (MTV <= 4 && WB == 4 && !lab_env("MI355Q_MOE_EXACT"))                                                       \
-            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, (MTV <= 4 && WB == 4)>), \
+        if (WB == 4 && !lab_env("MI355Q_MOE_EXACT"))                                                                   \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, WB == 4>),   \
                 dim3(tiles_m * tiles_n, a.ksplit), dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);               \
         else if (MTV <= 2 && !lab_env("MI355Q_PF_DEPTH2"))                                                             \
             hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \

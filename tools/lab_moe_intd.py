@@ -7,7 +7,7 @@ os.environ.setdefault("MI355Q_LIB", os.path.join(ROOT, "tensorrt-llm_amd", "lib"
 import torch, bench
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-for tok in (64, 128, 256):
+for tok in (64, 256, 512, 1024, 4096):
     res = {"intd": [], "exact": []}
     for rep in range(4):
         for name in ("intd", "exact"):
