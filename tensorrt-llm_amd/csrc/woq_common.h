@@ -153,6 +153,19 @@ __device__ __forceinline__ uint4 dequant8_int8(uint32_t w0, uint32_t w1, float s
     return r;
 }
 
+// 8 signed int8 (two dwords) -> the 8 integers as exact 16-bit floats (|q| <= 128 fits either mantissa): the fragment
+// of the deferred-scale form, whose per-column scale meets the accumulator in the epilogue
+template <typename T>
+__device__ __forceinline__ uint4 cvt8_i8(uint32_t w0, uint32_t w1)
+{
+    uint4 r;
+    r.x = pack2<T>(sbyte(w0, 0), sbyte(w0, 1));
+    r.y = pack2<T>(sbyte(w0, 2), sbyte(w0, 3));
+    r.z = pack2<T>(sbyte(w1, 0), sbyte(w1, 1));
+    r.w = pack2<T>(sbyte(w1, 2), sbyte(w1, 3));
+    return r;
+}
+
 template <int WBITS>
 struct Geo
 {

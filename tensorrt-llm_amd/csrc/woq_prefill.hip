@@ -149,7 +149,7 @@ PrefillPlan plan_prefill(int m, int n, int k, int wbits)
 template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int DEPTH = 2, int NW = PF_WAVES, bool INTD = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void woq_prefill_kernel(WoqArgs a, int tiles_m, int tiles_n)
 {
-    static_assert(!INTD || (WBITS == 4 && !ZERO && NSZ == 1), "integer domain with deferred scales: int4, per-column, no zeros");
+    static_assert(!INTD || (!ZERO && NSZ == 1), "integer domain with deferred scales: per-column, no zeros");
     constexpr int PF_TN = NB * 16 * NW;
     constexpr int KTILE = Geo<WBITS>::KTILE;   // 128 (int4) / 64 (int8) rows of k per weight tile
     constexpr int KSTEPS = Geo<WBITS>::KSTEPS; // MFMA k-steps per tile
@@ -371,9 +371,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
                 uint4 wf[NB];
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    wf[b] = unpack8_u4<T>(reinterpret_cast<const uint32_t*>(&t.w[b])[st]);
+                {
+                    const uint32_t* wd = reinterpret_cast<const uint32_t*>(&t.w[b]);
+                    if constexpr (WBITS == 4)
+                        wf[b] = unpack8_u4<T>(wd[st]);
+                    else // int8: q itself, exact in 16 bits; no offset, hence no S1
+                        wf[b] = cvt8_i8<T>(wd[2 * st], wd[2 * st + 1]);
+                }
                 const int coff = ((st * 4 + fk) ^ fsw) << 4;
-                constexpr int AF = MT - 1 < 3 ? MT - 1 : 3, R = AF + 1;
+                constexpr int AFW = NB == 2 ? 4 : 2;
+                constexpr int AF = MT - 1 < AFW ? MT - 1 : AFW, R = AF + 1;
                 const uint32_t abase = (uint32_t) (uintptr_t) (lds_void_t*) sa + (uint32_t) coff;
                 pf_u32x4_t av[R];
                 pf_static_for<AF>([&](auto jc) { pf_lds_read<decltype(jc)::value * 16 * RB>(av[decltype(jc)::value % R], abase); });
@@ -389,8 +396,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
                             acc[b][j] = mfma16<T>(wf[b], af, acc[b][j]);
-                        if (j % NW == wave) // wave-uniform
-                            s1all[j / NW] = mfma16<T>(ones, af, s1all[j / NW]);
+                        if constexpr (WBITS == 4)
+                            if (j % NW == wave) // wave-uniform
+                                s1all[j / NW] = mfma16<T>(ones, af, s1all[j / NW]);
                     });
             });
     };
@@ -557,17 +565,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         // the deferred scales: acc holds P = sum a u over this workgroup's k range, the waves' s1all the matching
         // sum a (every D row of an MFMA against ones is S1[m]: lanes 0 .. 15 hold it).  Shared through LDS -- the
         // k loop's buffers are free after its last barrier --, then out (or this split's slab) = s (P - 8 S1).
-        float* s1x = reinterpret_cast<float*>(lds);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < S1N; ++i)
-            if (wave + NW * i < MT && lane < 16)
-                s1x[(wave + NW * i) * 16 + lane] = s1all[i][0];
-        __syncthreads();
         float s1[MT];
+        if constexpr (WBITS == 4)
+        {
+            float* s1x = reinterpret_cast<float*>(lds);
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < MT; ++j)
-            s1[j] = s1x[j * 16 + em];
+            for (int i = 0; i < S1N; ++i)
+                if (wave + NW * i < MT && lane < 16)
+                    s1x[(wave + NW * i) * 16 + lane] = s1all[i][0];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                s1[j] = s1x[j * 16 + em];
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
         {
@@ -577,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             for (int j = 0; j < MT; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[b][j][i] = sv[i] * fmaf(-8.f, s1[j], acc[b][j][i]);
+                    acc[b][j][i] = WBITS == 4 ? sv[i] * fmaf(-8.f, s1[j], acc[b][j][i]) : sv[i] * acc[b][j][i];
         }
     }
     const float alpha = (a.alpha && a.ksplit == 1) ? a.alpha[0] : 1.f; // out = alpha * acc + bias
@@ -653,6 +664,18 @@ template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int NW = PF
 void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
 {
     const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 16 * NW);
+    if constexpr (WBITS == 8 && !ZERO && NSZ == 1 && MT >= 8)
+    {
+        // W8A16 per-channel (weightOnlyQuantMatmulPlugin's int8 form): the scale is the same for every k, so it is
+        // deferred to the epilogue -- the int8 values go to the MFMA as they are (12 vector-ALU operations per 8
+        // weights instead of 20, no scale registers through the loop); out = s * sum a q, one-hot rows give s q exactly
+        if (a.group_shift == 31 && !lab_env("MI355Q_W8_EXACT"))
+        {
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB, 2, NW, true>), dim3(tiles_m * tiles_n, a.ksplit),
+                dim3(NW * 64), 0, stream, a, tiles_m, tiles_n);
+            return;
+        }
+    }
     // (the 4-slot ring of the grouped MoE launch was measured here too, m = 40 - 64 at seven Llama shapes: 2 - 17 %
     // SLOWER than the ping-pong -- these launches are split over K into 4-tile pieces, a ring never fills)
     hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB, 2, NW>), dim3(tiles_m * tiles_n, a.ksplit),
@@ -1408,8 +1431,8 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (WB == 4 && !lab_env("MI355Q_MOE_EXACT"))                                                                   \
-            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, WB == 4>),   \
+        if (!lab_env("MI355Q_MOE_EXACT"))                                                                              \
+            hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2), PF_WAVES, true>),      \
                 dim3(tiles_m * tiles_n, a.ksplit), dim3(PF_WAVES * 64), 0, stream, a, tiles_m, tiles_n);               \
         else if (MTV <= 2 && !lab_env("MI355Q_PF_DEPTH2"))                                                             \
             hipLaunchKernelGGL((woq_prefill_kernel<T, WB, false, 1, MTV, 2, (MTV <= 2 ? 4 : 2)>), dim3(tiles_m * tiles_n, a.ksplit), \
