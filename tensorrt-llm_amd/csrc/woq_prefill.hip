@@ -664,11 +664,13 @@ template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int NW = PF
 void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
 {
     const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 16 * NW);
-    if constexpr (WBITS == 8 && !ZERO && NSZ == 1 && MT >= 8)
+    if constexpr (!ZERO && NSZ == 1 && NW == PF_WAVES && (WBITS == 4 || MT >= 8))
     {
-        // W8A16 per-channel (weightOnlyQuantMatmulPlugin's int8 form): the scale is the same for every k, so it is
-        // deferred to the epilogue -- the int8 values go to the MFMA as they are (12 vector-ALU operations per 8
-        // weights instead of 20, no scale registers through the loop); out = s * sum a q, one-hot rows give s q exactly
+        // per-channel scales without zeros (weightOnlyQuantMatmulPlugin's forms): the scale is the same for every k, so
+        // it is deferred to the epilogue.  int8: the values go to the MFMA as they are (12 vector-ALU operations per 8
+        // weights instead of 20, no scale registers through the loop), out = s * sum a q.  int4: the integer-domain
+        // tiles of the grouped MoE launch, out = s (P - 8 S1).  One-hot rows give s q exactly either way.  (Not the
+        // 256 x 256 tile: MFMA-bound, see moe_weight_only_gemm.)
         if (a.group_shift == 31 && !lab_env("MI355Q_W8_EXACT"))
         {
             hipLaunchKernelGGL((woq_prefill_kernel<T, WBITS, ZERO, NSZ, MT, NB, 2, NW, true>), dim3(tiles_m * tiles_n, a.ksplit),
