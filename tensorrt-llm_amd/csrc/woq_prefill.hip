@@ -1171,9 +1171,12 @@ void launch_skinny(const WoqArgs& a, const SkinnyPlan& s, float* partials, uint3
 #define MQ_SKINNY(MTV, PV)                                                                                             \
     hipLaunchKernelGGL((woq_skinny_kernel<T, WBITS, ZERO, NSZ, MTV, PV>), grid, dim3(256), 0, stream, a, s.tiles_m,    \
         s.tiles_n, s.pieces, partials, arrive, stamps)
-    if (s.mt == 4)
+#ifdef MI355Q_LAB
+    if (s.mt == 4) // (64-row tiles with 4 k-tiles: measured and left to the lab)
         MQ_SKINNY(4, 4);
-    else if (s.p == 8)
+    else
+#endif
+    if (s.p == 8)
         MQ_SKINNY(2, 8);
     else
         MQ_SKINNY(2, 4);
