@@ -303,6 +303,12 @@ def test_workspace_size_queries_are_pure_host():
     # the answer covers every m' <= m (an engine is built for a maximum m): monotonic in m, also between 16-steps
     ws = [L.lib().mi355q_weight_only_gemm_workspace_size(m, 2048, 8192, 2) for m in range(1, 70)]
     assert all(b >= a for a, b in zip(ws, ws[1:])) and ws[23] > ws[15]
+    # 32 < m <= 64 at a cfg4 slice: the skinny GEMM's partial tiles (2 m-tiles x 28 n-tiles x 8 pieces of 32 x 128 fp32)
+    # behind the smoothed activations
+    act = lambda m, k: (m * k * 2 + 255) // 256 * 256
+    assert L.lib().mi355q_weight_only_gemm_workspace_size(64, 3584, 8192, 2) >= act(64, 8192) + 2 * 28 * 8 * 32 * 128 * 4
+    ws = [L.lib().mi355q_weight_only_gemm_workspace_size(m, 3584, 8192, 2) for m in range(30, 70)]
+    assert all(b >= a for a, b in zip(ws, ws[1:]))
     p = L.DecodeAttentionParams()
     p.batch, p.num_heads, p.num_kv_heads, p.head_size = 64, 8, 1, 128
     p.max_blocks_per_seq, p.tokens_per_block, p.max_seq_len = 32, 64, 2048
