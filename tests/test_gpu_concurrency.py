@@ -104,3 +104,80 @@ def test_two_graphs_and_an_eager_stream_run_concurrently(cuda):
         torch.cuda.synchronize()
         for s, ref, name in ((a, alone[0], "graph A"), (b, alone[1], "graph B"), (c, alone[2], "eager stream")):
             s.verify(ref, f"round {rnd}, {name}")
+
+
+class _Gemm:
+    """One W4A16 GEMM through mi355q_weight_only_gemm with every buffer preallocated (its own workspace: the partial
+    tiles of the in-launch split-K are the caller's; the arrival words are the library's)."""
+
+    def __init__(self, dev, m, n, k, seed):
+        g = torch.Generator().manual_seed(seed)
+        dt = torch.bfloat16
+        self.w = torch.randint(-128, 128, (k, n // 2), dtype=torch.int8, generator=g).to(dev)   # any bytes are int4 tiles
+        self.scale = (torch.rand(k // 128, n, generator=g) * 0.02 + 0.001).to(dt).to(dev)
+        self.zero = (torch.randn(k // 128, n, generator=g) * 0.05).to(dt).to(dev)
+        self.act = torch.randn(m, k, generator=g).to(dt).to(dev)
+        self.out = torch.zeros(m, n, dtype=dt, device=dev)
+        need = L.lib().mi355q_weight_only_gemm_workspace_size(m, n, k, L.WEIGHT_INT4)
+        self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        p = L.WeightOnlyParams()
+        p.qweight, p.scales, p.zeros = self.w.data_ptr(), self.scale.data_ptr(), self.zero.data_ptr()
+        p.in_, p.out = self.act.data_ptr(), self.out.data_ptr()
+        p.m, p.n, p.k, p.group_size = m, n, k, 128
+        p.weight_type, p.act_type = L.WEIGHT_INT4, L.BF16
+        p.workspace, p.workspace_bytes = self.ws.data_ptr(), need
+        self.p = p
+
+    def launch(self):
+        L.check(L.lib().mi355q_weight_only_gemm(C.byref(self.p), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def alone(self):
+        self.out.zero_()
+        self.launch()
+        torch.cuda.synchronize()
+        res = self.out.clone()
+        self.out.zero_()
+        return res
+
+
+def test_split_k_gemms_in_two_graphs_replayed_concurrently(cuda):
+    # the GEMMs that close their split-K inside the launch -- the light GEMV (m = 1, a cfg4 slice: 8 k-segments per n-block)
+    # and the skinny GEMM (m = 64: 8 pieces per tile) -- count arrivals on library words as well: captured into two graphs
+    # at different times, replayed together on two streams next to eager launches of both on a third and on the default
+    # stream; every result bit for bit what the same launch gives alone
+    dev = cuda
+    ga = [_Gemm(dev, 1, 1280, 8192, 1), _Gemm(dev, 64, 3584, 8192, 2)]
+    gb = [_Gemm(dev, 4, 3584, 8192, 3), _Gemm(dev, 40, 1280, 8192, 4)]
+    ge = [_Gemm(dev, 1, 1280, 8192, 5), _Gemm(dev, 64, 3584, 8192, 6)]
+    want = [[g.alone() for g in grp] for grp in (ga, gb, ge)]
+
+    def capture(grp):
+        side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for g in grp:
+                    g.launch()
+        return graph
+
+    graph_a = capture(ga)
+    for _ in range(40):          # eager traffic between the two captures
+        for g in ge:
+            g.launch()
+    graph_b = capture(gb)
+    torch.cuda.synchronize()
+    for g in ge:
+        g.out.zero_()
+    sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(6):
+        with torch.cuda.stream(sa):
+            graph_a.replay()
+        with torch.cuda.stream(sb):
+            graph_b.replay()
+        with torch.cuda.stream(sc):
+            ge[0].launch()
+        ge[1].launch()
+        torch.cuda.synchronize()
+        for grp, exp in zip((ga, gb, ge), want):
+            for g, e in zip(grp, exp):
+                assert torch.equal(g.out.view(torch.int16), e.view(torch.int16)), f"repetition {rep}: m={g.p.m} n={g.p.n}"
+                g.out.zero_()
