@@ -101,6 +101,10 @@ struct CtxArgs
     const uint16_t* rel_bias;
     int rel_stride, max_distance;
     int dh_pad; // row length of `proc`: head_size, or the 64 / 128 it is padded to (zeros) for the attention kernel
+    int q_from_input;  // the attention kernel takes q straight from the qkv rows (bias add + rotation in its prologue, the
+                       // angles from cs_table): the fast prepare kernel then skips the q vectors altogether
+    float2* cs_table;  // [rows][64] (cos, sin) of pair j at the row's position, written by the fast prepare kernel for
+                       // q_from_input (it lives in the q part of `proc`, which nothing else uses then)
     int kv_from_cache; // the attention kernel reads K / V from the cache this call appends to (16-bit cache, every token at its
                        // own slot): the fast prepare kernel then writes K / V once, not to the workspace as well
     int raw_k_cache; // POS_SHIFT: K goes to the cache without the position embedding (k_wo_pos,
@@ -296,6 +300,8 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
             sincosf(ang, &sn, &cs);
             cs_tab[j] = cs;
             cs_tab[64 + j] = sn;
+            if (p.q_from_input)
+                p.cs_table[row * 64 + j] = make_float2(cs, sn);
         }
         __syncthreads();
     }
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void ctx_prepare_fast_kernel(CtxArgs p)
     const int blk = slot >> p.tpb_log2, tin = slot & (tpb - 1);
     const bool bp = ctx_has_cache(p) && ctx_keeps(p, pos, past + len);
     const float qs = (bp && p.kv_type) ? p.kv_scale_orig_quant[0] : 1.f;
-    for (int it = threadIdx.x; it < nvec * cpv; it += 256)
+    for (int it = (p.q_from_input ? Hq * cpv : 0) + threadIdx.x; it < nvec * cpv; it += 256)
     {
         const int vec = it / cpv, c = it % cpv;
         const int d0 = 8 * c, d1 = 8 * c + D / 2;
@@ -634,13 +640,113 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
     }
     else
     {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        if (p.q_from_input) // wave-uniform
         {
-            const int qr = min(q0 + 16 * qt + lr, len - 1); // rows past the sequence re-read its last row; never stored
+            // q straight from the qkv rows: the prepare pass's arithmetic for a q vector, in its order (bias add in T,
+            // rotation in fp32 with the angles the prepare pass tabulated, one rounding to T) -- the same bits it
+            // would have written to the workspace, without the round trip.  A lane's 8 elements of k-step ks are
+            // d = 32 ks + 8 lq + i: NeoX pairs (d, d + Dh/2) are k-steps (ks, ks + KS/2) of the same lane, GPT-J pairs
+            // (2 j, 2 j + 1) neighbours inside the chunk.
+            const int hidden = (p.num_heads + 2 * p.num_kv_heads) * DH;
+            const bool rope = p.pos_type == 1 || p.pos_type == 2;
+            const int half = p.rot_dim >> 1;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qf[qt][ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * DH + 32 * ks + 8 * lq);
+            for (int qt = 0; qt < 2; ++qt)
+            {
+                const int qr = min(q0 + 16 * qt + lr, len - 1);
+                const uint16_t* src = p.qkv + (row0 + qr) * (size_t) hidden + (size_t) h * DH + 8 * lq;
+                float x[KS][8];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                {
+                    const uint4 r = *reinterpret_cast<const uint4*>(src + 32 * ks);
+                    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        x[ks][2 * i] = T16<T>::lo(w[i]);
+                        x[ks][2 * i + 1] = T16<T>::hi(w[i]);
+                    }
+                    if (p.qkv_bias)
+                    {
+                        const uint4 bb = *reinterpret_cast<const uint4*>(p.qkv_bias + (size_t) h * DH + 32 * ks + 8 * lq);
+                        const uint32_t bw[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                        {
+                            x[ks][2 * i] = T16<T>::to_float(T16<T>::from_float(x[ks][2 * i] + T16<T>::lo(bw[i])));
+                            x[ks][2 * i + 1] = T16<T>::to_float(T16<T>::from_float(x[ks][2 * i + 1] + T16<T>::hi(bw[i])));
+                        }
+                    }
+                }
+                if (rope)
+                {
+                    const float2* tab = p.cs_table + (row0 + qr) * 64;
+                    if (p.pos_type == 2) // NeoX, rot_dim == Dh
+                    {
+#pragma unroll
+                        for (int ks = 0; ks < KS / 2; ++ks)
+                        {
+                            const float4* t4 = reinterpret_cast<const float4*>(tab + 32 * ks + 8 * lq);
+#pragma unroll
+                            for (int i2 = 0; i2 < 4; ++i2)
+                            {
+                                const float4 cs2 = t4[i2]; // (cos, sin) of pairs 2 i2, 2 i2 + 1
+                                const float cs[2] = {cs2.x, cs2.z}, sn[2] = {cs2.y, cs2.w};
+#pragma unroll
+                                for (int e = 0; e < 2; ++e)
+                                {
+                                    const int i = 2 * i2 + e;
+                                    const float a = x[ks][i], c2 = x[ks + KS / 2][i];
+                                    x[ks][i] = cs[e] * a - sn[e] * c2;
+                                    x[ks + KS / 2][i] = cs[e] * c2 + sn[e] * a;
+                                }
+                            }
+                        }
+                    }
+                    else // GPT-J: pair j = (32 ks + 8 lq) / 2 + i2, elements past rot_dim pass through
+                    {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                        {
+                            const int j0 = 16 * ks + 4 * lq;
+                            const float4* t4 = reinterpret_cast<const float4*>(tab + min(j0, 60));
+#pragma unroll
+                            for (int i2 = 0; i2 < 2; ++i2)
+                            {
+                                const float4 cs2 = t4[i2];
+                                const float cs[2] = {cs2.x, cs2.z}, sn[2] = {cs2.y, cs2.w};
+#pragma unroll
+                                for (int e = 0; e < 2; ++e)
+                                {
+                                    const int jj = 2 * i2 + e;
+                                    if (j0 + jj < half)
+                                    {
+                                        const float a = x[ks][2 * jj], c2 = x[ks][2 * jj + 1];
+                                        x[ks][2 * jj] = cs[e] * a - sn[e] * c2;
+                                        x[ks][2 * jj + 1] = cs[e] * c2 + sn[e] * a;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    qf[qt][ks] = make_uint4(pack2<T>(x[ks][0], x[ks][1]), pack2<T>(x[ks][2], x[ks][3]), pack2<T>(x[ks][4], x[ks][5]),
+                        pack2<T>(x[ks][6], x[ks][7]));
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+            {
+                const int qr = min(q0 + 16 * qt + lr, len - 1); // rows past the sequence re-read its last row; never stored
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    qf[qt][ks] = *reinterpret_cast<const uint4*>(qbase + (size_t) qr * DH + 32 * ks + 8 * lq);
+            }
         }
         // make the compiler's own vmcnt bookkeeping for the Q loads end here, before any (invisible to it) DMA is in
         // flight: otherwise it places its waits for them at their first use inside the loop, where they would drain the
@@ -1194,6 +1300,19 @@ void context_attention(const mi355q_context_attention_params& q, hipStream_t str
     const bool from_cache = !cached && fast && has_cache && a.kv_type == 0 && !windowed && q.sink_token_length == 0
         && (q.head_size == 64 || q.head_size == 128) && (q.num_heads <= 2 * q.num_kv_heads || lab_env("MI355Q_CTX_ONE_COPY"))
         && !lab_env("MI355Q_CTX_TWO_COPIES");
+    // q without the round trip through the workspace: the attention kernel's prologue does the prepare pass's work for its
+    // own q rows (context_attn.hip, q_from_input); the rotation angles come from a table the prepare pass writes into the
+    // (then unused) q part of the workspace
+    bool w32_lab = false;
+#ifdef MI355Q_LAB
+    w32_lab = lab_env("MI355Q_CTX_W32") != nullptr;
+#endif
+    if (fast && (q.head_size == 64 || q.head_size == 128) && (size_t) q.num_heads * q.head_size * 2 >= 64 * sizeof(float2) && !w32_lab
+        && !lab_env("MI355Q_CTX_Q_PASS"))
+    {
+        a.q_from_input = 1;
+        a.cs_table = reinterpret_cast<float2*>(a.proc);
+    }
     if (from_cache)
     {
         a.kv_from_cache = 1;
