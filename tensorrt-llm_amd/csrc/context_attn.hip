@@ -622,6 +622,13 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
     const int ntiles = (kv_end + CTX_KT - 1) / CTX_KT;
     const int tile_lo = max(past + Q0 - window, 0) / CTX_KT; // sliding window: first key the workgroup's first row sees
 
+    // the first K / V tile goes out before the q prologue: its round trip then runs under the q loads (and, with
+    // q_from_input, under the bias add and the rotation) instead of after them.  vmcnt retires in order, so the waits
+    // hipcc places for the q loads also cover these DMAs -- which the loop needs before its first tile anyway.
+    fetch_blocks(tile_lo);
+    stage(tile_lo, tile_lo & 1);
+    fetch_blocks(min(tile_lo + 1, ntiles - 1));
+
     // Q^T fragments (B operand).  16x16x32: column = query row q0 + 16*qt + lr, k = d = 32*ks + 8*lq + j.
     // 32x32x16: column = query row q0 + L, k = d = 16*ks + 8*hh + j  (L = lane & 31, hh = lane >> 5)
     constexpr int KS16 = DH / 16, DB = DH / 32;
@@ -757,9 +764,6 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(DH > 1
             for (int ks = 0; ks < KS; ++ks)
                 asm volatile("" : "+v"(qf[qt][ks].x), "+v"(qf[qt][ks].y), "+v"(qf[qt][ks].z), "+v"(qf[qt][ks].w));
     }
-    fetch_blocks(tile_lo);
-    stage(tile_lo, tile_lo & 1);
-    fetch_blocks(min(tile_lo + 1, ntiles - 1));
     const float sscale_in = p.score_scale * 1.4426950408889634f;
     // BIAS: the scores are scaled and biased in place (log2 domain), the softmax then runs with scale 1
     const float sscale = BIAS ? 1.f : sscale_in;
