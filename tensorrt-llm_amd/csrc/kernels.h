@@ -17,7 +17,7 @@ void symmetric_quantize(int8_t* processed, int8_t* unprocessed, float* scales, c
 int woq_choose_ksplit(int m, int n, int k, int weight_type);
 size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type);
 void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream);
-bool woq_gemm_fuses_act_scale(int m, int n, int k); // then weight_only_gemm accepts p.act_scale (no separate smoothing pass)
+bool woq_gemm_fuses_act_scale(int m, int n, int k, int weight_type, bool has_act_scale); // true: a decode kernel takes the call and applies p.act_scale itself (no separate smoothing pass)
 void weight_only_dequantize(const mi355q_weight_only_params& p, hipStream_t stream);
 
 // woq_gemv_small.hip: the light decode GEMV (m <= 16, one launch, in-launch split-K)

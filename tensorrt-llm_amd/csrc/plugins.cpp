@@ -1782,10 +1782,10 @@ void weight_only_gemm_entry(const mi355q_weight_only_params& p, hipStream_t stre
         ws += act_bytes;
         ws_bytes -= act_bytes;
     }
-    else if (p.act_scale && !woq_gemm_fuses_act_scale(p.m, p.n, p.k))
+    else if (p.act_scale && !woq_gemm_fuses_act_scale(p.m, p.n, p.k, p.weight_type, true))
     {
         // weightOnlyGroupwiseQuantMatmulPlugin.cpp:382-418: smoothed activations go to the workspace (the decode
-        // kernel, m <= 32, applies the scale while it stages the rows instead: one launch less)
+        // kernels, m <= 32, apply the scale while they stage the rows instead: one launch less)
         const size_t act_bytes = align_up((size_t) p.m * p.k * 2, 256);
         MQ_CHECK(ws && ws_bytes >= act_bytes, "workspace too small for the smoothed activations (%zu < %zu)", ws_bytes,
             act_bytes);

@@ -815,23 +815,24 @@ size_t woq_gemm_workspace_size(int m, int n, int k, int weight_type)
     // worst case over all m' <= m of ksplit(m') * m' * n fp32 slabs
     size_t best = 0;
     for (int mm = 1; mm <= m; mm = (mm < 64 || m - mm < 16) ? mm + 1 : mm + 16) // every m' up to 64, then 16s, then m
-    {
-        if (woq_gemm_fuses_act_scale(mm, n, k))
+        for (int pre = 0; pre < 2; ++pre) // the route can depend on whether the call carries a pre-quant scale
         {
-            const LightPlan lp = woq_light_plan(mm, n, k, weight_type);
-            if (lp.applies)
+            const bool decode = woq_gemm_fuses_act_scale(mm, n, k, weight_type, pre != 0);
+            if (decode)
             {
-                best = std::max(best, lp.workspace_bytes);
-                continue;
+                const LightPlan lp = woq_light_plan(mm, n, k, weight_type);
+                if (lp.applies)
+                {
+                    best = std::max(best, lp.workspace_bytes);
+                    continue;
+                }
             }
+            else
+                best = std::max(best, woq_skinny_workspace_size(mm, n, k, weight_type));
+            const int s = decode ? woq_choose_ksplit(mm, n, k, weight_type) : woq_prefill_ksplit(mm, n, k, weight_type);
+            if (s > 1)
+                best = std::max(best, (size_t) s * mm * n * sizeof(float));
         }
-        if (!woq_gemm_fuses_act_scale(mm, n, k))
-            best = std::max(best, woq_skinny_workspace_size(mm, n, k, weight_type));
-        const int s = !woq_gemm_fuses_act_scale(mm, n, k) ? woq_prefill_ksplit(mm, n, k, weight_type)
-                                                                             : woq_choose_ksplit(mm, n, k, weight_type);
-        if (s > 1)
-            best = std::max(best, (size_t) s * mm * n * sizeof(float));
-    }
     return best;
 }
 
@@ -848,11 +849,28 @@ void woq_splitk_reduce(const float* slabs, const void* bias, const float* alpha,
             (const uint16_t*) bias, alpha, (uint16_t*) out, m, n, ksplit);
 }
 
-// m <= 32 (or shapes the prefill GEMM does not take) run the decode kernel, which applies the pre-quant scale itself
-bool woq_gemm_fuses_act_scale(int m, int n, int k)
+// Which kernel family takes (m, n, k): true = the decode kernels (light / persistent GEMV), which apply the pre-quant
+// scale themselves; false = the MFMA GEMMs over staged activation tiles (skinny form / ping-pong prefill), which want
+// the activations smoothed beforehand.
+//   m <= 16: decode.  m > 32: the GEMMs (where the shape allows).
+//   16 < m <= 32 (tools/lab_skinny.py, MI355Q_GEMV_MAX_M=16 against 32): the persistent kernel's two 16-row chunks
+//   lose 3 - 20 % to the skinny form / the ping-pong at every decode-sized weight (4096 x 4096: 13.8 -> 11.0 us,
+//   22016 x 4096: 29.1 -> 23.5, 3584 x 8192: 17.6 -> 14.5) and win only beyond ~64 MB of weights (28672 x 8192: 45.5
+//   against 50 us).  With a pre-quant scale the GEMMs need the extra smoothing launch, which eats the difference: those
+//   calls stay on the decode kernel.
+bool woq_gemm_fuses_act_scale(int m, int n, int k, int weight_type, bool has_act_scale)
 {
-    static const int gemv_max_m = lab_env("MI355Q_GEMV_MAX_M") ? atoi(lab_env("MI355Q_GEMV_MAX_M")) : GEMV_MAX_M;
-    return !(m > gemv_max_m && woq_prefill_supported(m, n, k) && !lab_env("MI355Q_NO_PREFILL"));
+    static const int lab_max_m = lab_env("MI355Q_GEMV_MAX_M") ? atoi(lab_env("MI355Q_GEMV_MAX_M")) : 0;
+    if (!woq_prefill_supported(m, n, k) || lab_env("MI355Q_NO_PREFILL"))
+        return true;
+    if (lab_max_m > 0)
+        return m <= lab_max_m;
+    if (m <= 16)
+        return true;
+    if (m > GEMV_MAX_M)
+        return false;
+    const size_t wbytes = (size_t) n * k / (weight_type == MI355Q_WEIGHT_INT4 ? 2 : 1);
+    return has_act_scale || wbytes > ((size_t) 64 << 20);
 }
 
 void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_t workspace_bytes, hipStream_t stream)
@@ -861,7 +879,7 @@ void weight_only_gemm(const mi355q_weight_only_params& p, void* workspace, size_
     MQ_CHECK(p.in, "null activation");
     if (p.m == 0)
         return;
-    if (!woq_gemm_fuses_act_scale(p.m, p.n, p.k))
+    if (!woq_gemm_fuses_act_scale(p.m, p.n, p.k, p.weight_type, p.act_scale != nullptr))
     {
         MQ_CHECK(p.act_scale == nullptr, "pre-quant scale must be applied with mi355q_apply_per_channel_scale first");
         // m > 64: dequantise-in-registers MFMA GEMM (woq_prefill.hip); the decode kernel below would
