@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
                             acc[b][j] = mfma16<T>(wf[b], af, acc[b][j]);
-                        if constexpr (WBITS == 4)
+                        if constexpr (WBITS == 4 && INTD) // (the lambda's body is compiled for every instantiation)
                             if (j % NW == wave) // wave-uniform
                                 s1all[j / NW] = mfma16<T>(ones, af, s1all[j / NW]);
                     });

@@ -105,11 +105,13 @@ def test_groupwise_baseline_cfg1_shape(cuda, dtype_str, m):
     _groupwise_case(m, 4096, 4096, dtype_str, True, True, False, 128, cuda)
 
 
+@pytest.mark.parametrize("pre", [True, False])
 @pytest.mark.parametrize("m", [17, 24, 31, 32])
-def test_groupwise_two_row_chunks_large_k(cuda, m):
-    # 16 < m <= 32 stays on the decode kernel (two 16-row chunks per block); at k = 8192 its activation slab needs
-    # split-K, so the workspace query must cover every m' <= m, not only multiples of 16 (m = 24 used to fail)
-    _groupwise_case(m, 2048, 8192, "bfloat16", False, True, True, 128, cuda)
+def test_groupwise_two_row_chunks_large_k(cuda, m, pre):
+    # 16 < m <= 32.  With a pre-quant scale the call stays on the decode kernel (two 16-row chunks per block; at k = 8192
+    # its activation slab needs split-K, so the workspace query must cover every m' <= m, not only multiples of 16 --
+    # m = 24 used to fail); without one it takes the skinny form of the GEMM (ragged second m-block, 8 pieces per tile)
+    _groupwise_case(m, 2048, 8192, "bfloat16", pre, True, True, 128, cuda)
 
 
 @pytest.mark.parametrize("m,n,k,pre,zero,bias,gs,dtype_str", [
@@ -117,7 +119,7 @@ def test_groupwise_two_row_chunks_large_k(cuda, m):
     (40, 1024, 4096, False, False, True, 64, "bfloat16"), (64, 8192, 1024, False, True, True, 64, "float16"),
     (49, 2560, 2048, True, False, False, 128, "bfloat16"), (64, 128, 128, False, True, True, 128, "float16")])
 def test_groupwise_skinny_form(cuda, m, n, k, pre, zero, bias, gs, dtype_str):
-    # 32 < m <= 64 at decode-sized weights (the tensor-parallel slices of cfg4 at a few dozen sequences): the skinny form
+    # 16 < m <= 64 at decode-sized weights (the tensor-parallel slices of cfg4 at a few dozen sequences): the skinny form
     # of the GEMM -- one burst of loads per workgroup, integer-domain int4 arithmetic, split-K closed inside the launch
     # (woq_skinny_kernel).  Ragged last m-block, both group sizes, 1 .. 16 pieces per tile, one-piece tiles (no partials)
     _groupwise_case(m, n, k, dtype_str, pre, zero, bias, gs, cuda)
