@@ -42,6 +42,10 @@ struct WoqArgs
     // moe_row_map[r] % moe_row_mod of `act`; null = `act` is already in expert order
     const int32_t* moe_row_map;
     int moe_row_mod;
+    // the grouped launch in two parts (256-row tiles): moe_full_only = this launch takes an expert's whole TM-row tiles
+    // only; moe_tail_mod = 256: this launch takes what such a launch with 256-row tiles left, rows >= (rows / 256) * 256
+    // of every expert, in its own (shorter) tiles, 256 / TM of them per expert
+    int moe_full_only, moe_tail_mod;
     // gated activation fused into the epilogue (run_moe's w1 GEMM; doGatedActivationKernel, moe_kernels.cu:795-817): the
     // n columns are [linear | gate] halves of glu_inter columns each; a wave takes matching n-blocks of both halves and
     // stores T(T(linear) * T(act(T(gate)))) to out[m][glu_inter] -- no [m][2 inter] buffer, no second pass.  0 = off;

@@ -136,21 +136,43 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         // grouped form: m-tile index over all experts -> (expert, its m-tile); then this workgroup is an ordinary tile
         // of that expert's GEMM.  Everything here is wave-uniform (scalar loads); tiles past the last expert's leave.
         int64_t row0 = 0;
-        int tiles_before = 0, e = 0, rows = 0;
-        for (; e < a.moe_experts; ++e)
+        int e = 0, rows = 0, skip = 0;
+        if (a.moe_tail_mod)
         {
-            const int64_t end = a.moe_rows[e];
-            rows = (int) (end - row0);
-            const int t = (rows + TM - 1) / TM;
-            if (tm < tiles_before + t)
-                break;
-            tiles_before += t;
-            row0 = end;
+            // the tail part of a two-part launch (below): 256 / TM tiles per expert, indexed directly -- most of these
+            // workgroups find nothing to do, and two scalar loads are all they should cost
+            constexpr int PER = 256 / TM > 0 ? 256 / TM : 1;
+            e = tm / PER;
+            tm %= PER;
+            if (e >= a.moe_experts)
+                return;
+            row0 = e ? a.moe_rows[e - 1] : 0;
+            rows = (int) (a.moe_rows[e] - row0);
+            skip = rows & ~255;
+            if (tm * TM >= rows - skip)
+                return;
         }
-        if (e == a.moe_experts)
-            return;
-        tm -= tiles_before;
-        a.m = rows;
+        else
+        {
+            int tiles_before = 0;
+            for (; e < a.moe_experts; ++e)
+            {
+                const int64_t end = a.moe_rows[e];
+                rows = (int) (end - row0);
+                if (a.moe_full_only) // the main part of a two-part launch ends at the expert's last whole tile
+                    rows -= rows % TM;
+                const int t = (rows + TM - 1) / TM;
+                if (tm < tiles_before + t)
+                    break;
+                tiles_before += t;
+                row0 = end;
+            }
+            if (e == a.moe_experts)
+                return;
+            tm -= tiles_before;
+        }
+        row0 += skip;
+        a.m = rows - skip;
         moe_row0 = (int) row0;
         if (!a.moe_row_map)
             a.act += row0 * a.k;
@@ -848,15 +870,38 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
             ((p.total_rows + 127) / 128 + p.num_experts / 2) * (a.n / 128)))
     {
         mt = 16;
-        const int tm16 = (int) ((p.total_rows + 255) / 256) + p.num_experts, tn16 = a.n / 256;
+        // Two parts.  Every expert ends in a ragged tile (half empty on average: with 4096 tokens over 8 experts, 4 of the
+        // ~36 tiles held a handful of rows and cost a whole 256-row tile of MFMAs each).  The 256-row launch takes the
+        // experts' WHOLE tiles only; a second launch of 64-row integer-domain tiles takes each expert's remaining
+        // rows (< 256: at most 4 tiles per expert; tiles past an expert's end leave at once).  Disjoint output rows.
+        // (tools/lab_moe_two_parts.py, whole layer, uniform routing: 1024 rows per expert 3.08 -> 2.86 ms, 2048 rows 5.65 ->
+        // 5.45; 512 rows even; 384 rows 1.25 -> 1.35 -- one whole tile per expert fills the chip badly on its own: from 768)
+        const bool two_parts = p.total_rows >= (int64_t) 768 * p.num_experts && !lab_env("MI355Q_MOE_ONE_PART");
+        const int tm16 = (int) (two_parts ? p.total_rows / 256 : (p.total_rows + 255) / 256 + p.num_experts), tn16 = a.n / 256;
+        a.moe_full_only = two_parts ? 1 : 0;
         // (the exact dequantisation here: this tile is MFMA-bound, and the integer-domain form's extra MFMAs against ones
         // cost it 7 % -- 4096 tokens, fc1 1.86 vs 2.00 ms, tools/lab_moe_intd.py)
-        if (bf)
-            hipLaunchKernelGGL((woq_prefill_kernel<bf16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream, a,
-                tm16, tn16);
-        else
-            hipLaunchKernelGGL((woq_prefill_kernel<f16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream, a,
-                tm16, tn16);
+        if (tm16 > 0)
+        {
+            if (bf)
+                hipLaunchKernelGGL((woq_prefill_kernel<bf16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream,
+                    a, tm16, tn16);
+            else
+                hipLaunchKernelGGL((woq_prefill_kernel<f16_t, 4, false, 1, 16, 2, 2, 8>), dim3(tm16 * tn16, 1), dim3(512), 0, stream,
+                    a, tm16, tn16);
+        }
+        if (two_parts)
+        {
+            a.moe_full_only = 0;
+            a.moe_tail_mod = 256; // (the kernel's tail indexing is written for 256)
+            const int tmt = p.num_experts * 4, tnt = a.n / 128;
+            if (bf)
+                hipLaunchKernelGGL((woq_prefill_kernel<bf16_t, 4, false, 1, 4, 2, 2, PF_WAVES, true>), dim3(tmt * tnt, 1),
+                    dim3(PF_WAVES * 64), 0, stream, a, tmt, tnt);
+            else
+                hipLaunchKernelGGL((woq_prefill_kernel<f16_t, 4, false, 1, 4, 2, 2, PF_WAVES, true>), dim3(tmt * tnt, 1),
+                    dim3(PF_WAVES * 64), 0, stream, a, tmt, tnt);
+        }
         MQ_HIP(hipGetLastError());
         return 1;
     }
