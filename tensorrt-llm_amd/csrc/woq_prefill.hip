@@ -874,9 +874,11 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
         // ~36 tiles held a handful of rows and cost a whole 256-row tile of MFMAs each).  The 256-row launch takes the
         // experts' WHOLE tiles only; a second launch of 64-row integer-domain tiles takes each expert's remaining
         // rows (< 256: at most 4 tiles per expert; tiles past an expert's end leave at once).  Disjoint output rows.
-        // (tools/lab_moe_two_parts.py, whole layer, uniform routing: 1024 rows per expert 3.08 -> 2.86 ms, 2048 rows 5.65 ->
-        // 5.45; 512 rows even; 384 rows 1.25 -> 1.35 -- one whole tile per expert fills the chip badly on its own: from 768)
-        const bool two_parts = p.total_rows >= (int64_t) 768 * p.num_experts && !lab_env("MI355Q_MOE_ONE_PART");
+        // (tools/lab_moe_two_parts.py, whole layer, uniform routing, one part -> two: 1024 rows per expert 3.05 -> 2.92 ms,
+        // 2048 rows 5.65 -> 5.57; 768 rows 2.28 -> 2.38, 384 rows 1.25 -> 1.35.  Part of the gain at 1024 is the w2 GEMM's
+        // whole tiles filling exactly two rounds of the chip; below ~4 whole tiles per expert the main launch fills its
+        // last round badly on its own and the ragged tiles were hiding in that slack: from 1024)
+        const bool two_parts = p.total_rows >= (int64_t) 1024 * p.num_experts && !lab_env("MI355Q_MOE_ONE_PART");
         const int tm16 = (int) (two_parts ? p.total_rows / 256 : (p.total_rows + 255) / 256 + p.num_experts), tn16 = a.n / 256;
         a.moe_full_only = two_parts ? 1 : 0;
         // (the exact dequantisation here: this tile is MFMA-bound, and the integer-domain form's extra MFMAs against ones
@@ -894,6 +896,7 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
         {
             a.moe_full_only = 0;
             a.moe_tail_mod = 256; // (the kernel's tail indexing is written for 256)
+            // (64-row tail tiles: 128-row ones, two per expert, measured slower -- layer at 4096 tokens 2.96 vs 2.92 ms)
             const int tmt = p.num_experts * 4, tnt = a.n / 128;
             if (bf)
                 hipLaunchKernelGGL((woq_prefill_kernel<bf16_t, 4, false, 1, 4, 2, 2, PF_WAVES, true>), dim3(tmt * tnt, 1),

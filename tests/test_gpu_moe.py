@@ -80,10 +80,10 @@ def test_moe_gemm_prefill_sized_experts_big_tile(cuda, dtype_str):
 
 @pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
 def test_moe_gemm_two_part_launch(cuda, dtype_str):
-    # >= 768 rows per expert on average: the 256-row launch takes the experts' whole tiles only and a second launch of
+    # >= 1024 rows per expert on average: the 256-row launch takes the experts' whole tiles only and a second launch of
     # 64-row tiles their ragged ends (an exact multiple of 256: no tail; a single row: tail only; 6 and 20 rows past a
     # multiple; a tail of 255)
-    _case(cuda, [1030, 768, 1, 1300], 8192, 128, dtype_str, L.WEIGHT_INT4, "silu", True)
+    _case(cuda, [1030, 1536, 1, 1556], 8192, 128, dtype_str, L.WEIGHT_INT4, "silu", True)
     _case(cuda, [1024, 511, 2048], 8192, 192, dtype_str, L.WEIGHT_INT4, "identity", False)
 
 
