@@ -46,6 +46,9 @@ struct WoqArgs
     // only; moe_tail_mod = 256: this launch takes what such a launch with 256-row tiles left, rows >= (rows / 256) * 256
     // of every expert, in its own (shorter) tiles, 256 / TM of them per expert
     int moe_full_only, moe_tail_mod;
+    // prefill kernel: tiles are walked in groups of pf_group_m m-tiles x all n-tiles, m fastest inside a group
+    // (0: m fastest over the whole launch)
+    int pf_group_m;
     // gated activation fused into the epilogue (run_moe's w1 GEMM; doGatedActivationKernel, moe_kernels.cu:795-817): the
     // n columns are [linear | gate] halves of glu_inter columns each; a wave takes matching n-blocks of both halves and
     // stores T(T(linear) * T(act(T(gate)))) to out[m][glu_inter] -- no [m][2 inter] buffer, no second pass.  0 = off;

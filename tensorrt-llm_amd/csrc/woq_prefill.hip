@@ -128,8 +128,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         const int q = nwg / 8, r = nwg % 8, x = bid % 8;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
     }
-    const int tn = bid / tiles_m;
+    int tn = bid / tiles_m;
     int tm = bid % tiles_m;
+    if (a.pf_group_m > 0)
+    {
+        // Rasterisation for the tall tiles.  The workgroups an XCD holds at one time are consecutive here; with m fastest
+        // over the whole launch they are one column of m-tiles: one weight panel shared, every activation panel (4 x the
+        // bytes of a weight panel per tile: 16-bit against 4-bit) fetched by one workgroup only and fetched again by the
+        // XCD's next column.  Groups of G m-tiles x all n-tiles, m fastest inside: an XCD's 32 resident tiles are G
+        // activation panels x 32 / G weight panels.
+        const int G = a.pf_group_m;
+        const int gsz = G * tiles_n;
+        const int grp = bid / gsz, rem = bid - grp * gsz;
+        const int gm = min(G, tiles_m - grp * G); // the last group may be shorter
+        tm = __builtin_amdgcn_readfirstlane(grp * G + rem % gm);
+        tn = __builtin_amdgcn_readfirstlane(rem / gm);
+    }
     int moe_row0 = 0; // grouped form: the expert's first row in the expert-sorted order
     if (a.moe_rows)
     {
@@ -637,10 +651,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     }
 }
 
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int NW>
+void launch_prefill_mt_grouped(const WoqArgs& a, int tiles_m, int tiles_n, hipStream_t stream);
+
 template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int NW = PF_WAVES>
 void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
 {
     const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 16 * NW);
+    WoqArgs b = a;
+    b.pf_group_m = lab_env("MI355Q_PF_GROUP_M") ? atoi(lab_env("MI355Q_PF_GROUP_M")) : (MT == 16 ? 4 : 0);
+    return launch_prefill_mt_grouped<T, WBITS, ZERO, NSZ, MT, NB, NW>(b, tiles_m, tiles_n, stream);
+}
+
+template <typename T, int WBITS, bool ZERO, int NSZ, int MT, int NB, int NW>
+void launch_prefill_mt_grouped(const WoqArgs& a, int tiles_m, int tiles_n, hipStream_t stream)
+{
     if constexpr (!ZERO && NSZ == 1 && NW == PF_WAVES && (WBITS == 4 || MT >= 8))
     {
         // per-channel scales without zeros (weightOnlyQuantMatmulPlugin's forms): the scale is the same for every k, so
@@ -880,6 +905,7 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
         // last round badly on its own and the ragged tiles were hiding in that slack: from 1024)
         const bool two_parts = p.total_rows >= (int64_t) 1024 * p.num_experts && !lab_env("MI355Q_MOE_ONE_PART");
         const int tm16 = (int) (two_parts ? p.total_rows / 256 : (p.total_rows + 255) / 256 + p.num_experts), tn16 = a.n / 256;
+        a.pf_group_m = lab_env("MI355Q_PF_GROUP_M") ? atoi(lab_env("MI355Q_PF_GROUP_M")) : 4; // (tiles of one expert are adjacent m-tiles)
         a.moe_full_only = two_parts ? 1 : 0;
         // (the exact dequantisation here: this tile is MFMA-bound, and the integer-domain form's extra MFMAs against ones
         // cost it 7 % -- 4096 tokens, fc1 1.86 vs 2.00 ms, tools/lab_moe_intd.py)
@@ -895,6 +921,7 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
         if (two_parts)
         {
             a.moe_full_only = 0;
+            a.pf_group_m = 0;
             a.moe_tail_mod = 256; // (the kernel's tail indexing is written for 256)
             // (64-row tail tiles: 128-row ones, two per expert, measured slower -- layer at 4096 tokens 2.96 vs 2.92 ms)
             const int tmt = p.num_experts * 4, tnt = a.n / 128;

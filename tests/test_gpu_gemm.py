@@ -128,10 +128,11 @@ def test_groupwise_skinny_form(cuda, m, n, k, pre, zero, bias, gs, dtype_str):
 @pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
 @pytest.mark.parametrize("m,n,k,pre,zero,bias,gs", [(512, 32768, 256, False, True, False, 128),
                                                     (300, 32768, 320, True, True, True, 64),
-                                                    (1024, 16384, 192, False, False, True, 64)])
+                                                    (1024, 16384, 192, False, False, True, 64),
+                                                    (2304, 8192, 192, False, True, True, 64)])
 def test_groupwise_prefill_big_tile(cuda, dtype_str, m, n, k, pre, zero, bias, gs):
     # m >= 256 with enough 256 x 256 tiles to fill the chip: the 8-wave tile of the prefill kernel (ragged last m-tile,
-    # int4 half k-tile, both scale-group forms)
+    # int4 half k-tile, both scale-group forms; 9 m-tiles: the tile walk's groups of 4 m-tiles end in a group of one)
     _groupwise_case(m, n, k, dtype_str, pre, zero, bias, gs, cuda)
 
 
