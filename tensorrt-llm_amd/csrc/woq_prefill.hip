@@ -659,7 +659,11 @@ void launch_prefill_mt(const WoqArgs& a, hipStream_t stream)
 {
     const int tiles_m = (a.m + MT * 16 - 1) / (MT * 16), tiles_n = a.n / (NB * 16 * NW);
     WoqArgs b = a;
-    b.pf_group_m = lab_env("MI355Q_PF_GROUP_M") ? atoi(lab_env("MI355Q_PF_GROUP_M")) : (MT == 16 ? 4 : 0);
+    // groups of 4 m-tiles for the 256-row tiles, 8 for the 128-row ones (twice the resident tiles per XCD, half the
+    // activation panel: W8A16 4096 x 4096 x 11008 375 -> 348 us, 4096 x 11008 x 4096 430 -> 405; nothing to gain below)
+    b.pf_group_m = MT == 16 ? 4 : (MT == 8 ? 8 : 0);
+    if (const char* e = lab_env(MT == 16 ? "MI355Q_PF_GROUP_M" : "MI355Q_PF_GROUP_M8"))
+        b.pf_group_m = atoi(e);
     return launch_prefill_mt_grouped<T, WBITS, ZERO, NSZ, MT, NB, NW>(b, tiles_m, tiles_n, stream);
 }
 
@@ -937,6 +941,8 @@ int moe_weight_only_gemm(const mi355q_moe_gemm_params& p, hipStream_t stream, bo
     }
     const int tiles_m = (int) ((p.total_rows + mt * 16 - 1) / (mt * 16)) + p.num_experts;
     const int tiles_n = a.n / 128;
+    // (the grouped tile walk below the 256-row tile: +4 % at 512 and 2048 tokens, -5 % at 1024 -- not taken)
+    a.pf_group_m = lab_env("MI355Q_PF_GROUP_M_MOE") ? atoi(lab_env("MI355Q_PF_GROUP_M_MOE")) : 0;
 #define MQ_MOE(T, WB, MTV)                                                                                             \
     do                                                                                                                 \
     {                                                                                                                  \
