@@ -32,7 +32,11 @@ def durations(d):
         for r in csv.DictReader(open(f)):
             if "mi355q" not in r["Kernel_Name"]:
                 continue
-            key = (short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "?")))
+            if "Grid_Size_X" in r:  # the counter files give the product of the three dimensions
+                grid = str(int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
+            else:
+                grid = r.get("Grid_Size", "?")
+            key = (short(r["Kernel_Name"]), grid)
             out[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
     return out
 
