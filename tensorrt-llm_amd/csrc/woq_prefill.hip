@@ -778,9 +778,14 @@ void weight_only_prefill_gemm(const WoqArgsHost& h, hipStream_t stream)
 // Tile height of the grouped MoE launch.  The host sees only the total row count, but with real routing the experts'
 // row counts scatter around the average (about a binomial: sigma^2 ~ avg (1 - 1/experts)), and a workgroup tile that the
 // average fills exactly is half wasted on every expert that got a few rows more.  Expected padded rows per expert
-// E[ceil(r / TM)] TM for r ~ N(avg, sigma^2), weighted by how well each tile height runs (tools/lab_moe_mt.py: 64-row
-// tiles 0.87, 128-row 1.0, the 256 x 256 / 8-wave tile 1.16); 32-row tiles (with their deeper ring) while the launch is a
-// weight stream (<= 24 rows per expert).
+// E[ceil(r / TM)] TM for r ~ N(avg, sigma^2), weighted by how well each tile height runs.  The weights were re-measured on
+// the WHOLE LAYER under random routing once the integer-domain tiles and the grouped tile walk existed
+// (tools/lab_moe_tile_layer.py; time per padded row): 64-row tiles 1.0, 128-row 0.98, the 256 x 256 / 8-wave tile 1.15
+// -- but the tall tile only from 768 rows per expert: below that its few tiles fill the chip badly in the w2 GEMM and
+// half of its rows are padding (192 / 384 / 512 / 640 rows per expert: 64-row tiles 754 / 1315 / 1730 / 2066 us against
+// 1050 / 1720 / 1960 / 2212; 768 rows: 2450 against 2414; 1024 rows: 3220 against 3020).  The earlier weights (0.87 / 1.0 / 1.16) came from the bare GEMM with perfectly
+// balanced experts, which flatters tall tiles.  32-row tiles (with their deeper ring) while the launch is a weight
+// stream (<= 24 rows per expert).
 double moe_expected_padded_rows(double avg, double sigma, int tm)
 {
     auto cdf = [&](double x) { return 0.5 * (1.0 + std::erf((x - avg) / (sigma * 1.4142135623730951))); };
@@ -801,8 +806,8 @@ int moe_pick_tile(int64_t total_rows, int experts, bool allow256)
     if (avg <= 24.0)
         return 2;
     const double sigma = std::sqrt(std::max(1.0, avg * (1.0 - 1.0 / std::max(2, experts))));
-    const double c4 = moe_expected_padded_rows(avg, sigma, 64) / 0.87, c8 = moe_expected_padded_rows(avg, sigma, 128);
-    const double c16 = allow256 ? moe_expected_padded_rows(avg, sigma, 256) / 1.16 : 1e30;
+    const double c4 = moe_expected_padded_rows(avg, sigma, 64), c8 = moe_expected_padded_rows(avg, sigma, 128) / 0.98;
+    const double c16 = allow256 && avg >= 768.0 ? moe_expected_padded_rows(avg, sigma, 256) / 1.15 : 1e30;
     if (c16 < c8 && c16 < c4)
         return 16;
     return c4 < c8 ? 4 : 8;

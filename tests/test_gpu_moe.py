@@ -72,8 +72,11 @@ def test_moe_gemm_decode_and_prefill_row_counts(cuda):
 
 @pytest.mark.parametrize("dtype_str", ["float16", "bfloat16"])
 def test_moe_gemm_prefill_sized_experts_big_tile(cuda, dtype_str):
-    # >= 256 rows per expert on average, int4, n large enough for prefer_tile256: the 256 x 256 / 8-wave tile of the
-    # grouped launch; ragged experts (one empty, one of a single row, one straddling two tiles), bias + activation epilogue
+    # 768 .. 1023 rows per expert on average, int4, n large enough for prefer_tile256: the 256 x 256 / 8-wave tile of the
+    # grouped launch in one part; ragged experts (one empty, one of a single row, tiles straddled), bias + activation
+    # epilogue.  Then the sizes this test used to run (256 - 356 rows per expert), which take 64-row tiles now.
+    _case(cuda, [900, 0, 1, 2300], 8192, 128, dtype_str, L.WEIGHT_INT4, "identity", False)
+    _case(cuda, [780, 1020, 700], 8192, 192, dtype_str, L.WEIGHT_INT4, "silu", True)
     _case(cuda, [600, 0, 1, 423], 8192, 128, dtype_str, L.WEIGHT_INT4, "identity", False)
     _case(cuda, [257, 511, 300], 8192, 192, dtype_str, L.WEIGHT_INT4, "silu", True)
 
